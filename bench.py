@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/s of the HIP hot path (BASELINE.json metric), one JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one batched MobiEnvironment.step() over all envs of a rank = ONE kernel launch.
+Workload at N=1: BASELINE.json configs[1] -- 4096 envs, 4 UAV x 20 UE (groups 5,5,5,5), G=100, on-device
+Philox randomness, uniform random joint actions resident in HBM before the timed region, compact
+outputs only (no dense observation).  N>1: the same workload per rank (weak scaling); env instances are
+independent, so there is NO data-path collective -- only the barrier/max-reduce of the timing.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_BS, N_UE, GRID, GROUPS = 4, 20, 100, [5, 5, 5, 5]
+SEED = 0x5EED
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_env_step(U, B, Gr):
+    """compact state read+write + outputs, on-device RNG."""
+    return 48 * U + 2 * ((U + 7) // 8) + 96 * Gr + 16 * B + 45
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Times the CPU oracle (oracle/, kind 'port': scalar C restatement of the reference's step())
+    on a bounded sample of the same workload, one shard per host thread."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    per = 64
+    cfg = O.make_config(N_BS, N_UE, GRID, groups=GROUPS)
+    envs = [O.OracleEnv(cfg, per, seed=SEED, env_id_base=i * per) for i in range(cores)]
+    for e in envs:
+        e.construct()
+    rs = np.random.RandomState(1234)
+    acts = rs.randint(0, 625, size=(256, per)).astype(np.int64)
+    # calibrate on one thread, then size the sample for ~target_seconds
+    t0 = time.perf_counter()
+    for t in range(20):
+        envs[0].step(acts[t])
+    dt = (time.perf_counter() - t0) / 20
+    steps = int(max(50, min(20000, target_seconds / max(dt, 1e-9))))
+
+    def work(env):
+        for t in range(steps):
+            env.step(acts[t % 256])
+
+    th = [threading.Thread(target=work, args=(e,)) for e in envs]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    return {"value": cores * per * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d envs x %d steps of oracle step() (4 UAV x 20 UE, G=100, Philox), %.1f s"
+                      % (cores, per, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    E, K, W = args.envs, args.steps, args.warmup
+    env = BatchedMobiEnv(E, nBS=N_BS, nUE=N_UE, grid_n=GRID, groups=GROUPS, device=dev, seed=SEED,
+                         env_id_base=rank * E)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    n_act = min(K + W, 512)  # action table resident in HBM, cycled
+    actions = torch.randint(0, env.action_space_dim, (n_act, E), generator=gen, dtype=torch.int64).to(dev)
+    max_step = int(env.cfg.max_step)
+
+    def run(n, start):
+        for t in range(start, start + n):
+            env.step(actions[t % n_act])
+            if (t + 1) % max_step == 0:  # the reference's callers reset on `done` (main.py:205-211)
+                env.reset()
+
+    run(W, 0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K, W)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([elapsed, gpu_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_env_steps = world * E * K
+        per_launch_s = gpu_ms * 1e-3 / K  # average launch-to-launch time of the step kernel (HIP events)
+        b_step = algorithmic_bytes_per_env_step(N_UE, N_BS, len(GROUPS))
+        achieved = b_step * E / per_launch_s / 1e9
+        line = {
+            "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": total_env_steps / elapsed,
+            "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d batched envs/GPU, 4 UAV x 20 UE (groups 5,5,5,5), G=100, HIP step(), "
+                                   "compact outputs, on-device Philox, one launch per step" % E,
+                       "envs_per_gpu": E, "n_bs": N_BS, "n_ue": N_UE, "grid": GRID, "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "env_kernel<4,MODE_STEP>", "algorithmic_bytes_per_launch": b_step * E,
+                         "avg_launch_us": per_launch_s * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""ctypes binding of include/uavenv.h.  This is the only place the package touches libuavenv.so.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, construction of an env
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+MAX_GROUPS, MAX_BS = 16, 32
+_P = C.c_void_p
+
+
+class UavEnvConfig(C.Structure):
+    _fields_ = [
+        ("n_bs", C.c_int32), ("n_ue", C.c_int32), ("n_groups", C.c_int32), ("grid", C.c_int32),
+        ("group_size", C.c_int32 * MAX_GROUPS), ("bs_init_xy", (C.c_int32 * 2) * MAX_BS),
+        ("max_step", C.c_int32), ("bs_step", C.c_int32), ("min_bs_dist", C.c_int32), ("n_act", C.c_int32),
+        ("agg_init", C.c_int32), ("deagg_len", C.c_int32), ("agg_len", C.c_int32), ("_pad", C.c_int32),
+        ("grid_width", C.c_double), ("p_bs_dbm", C.c_double), ("noise_dbm", C.c_double),
+        ("pl_a", C.c_double), ("pl_b", C.c_double), ("pl_dis", C.c_double),
+        ("antenna_gain", C.c_double), ("eq_loss", C.c_double),
+        ("shadow_mean", C.c_double), ("shadow_sd", C.c_double),
+        ("ho_thresh_db", C.c_double), ("out_thresh", C.c_double),
+        ("ue_velocity", C.c_double), ("grp_v_min", C.c_double), ("grp_v_max", C.c_double),
+        ("aggregation", C.c_double),
+    ]
+
+
+class UavEnvInitInject(C.Structure):
+    _fields_ = [(n, _P) for n in ("u_x_dev", "u_y_dev", "u_th_dev", "u_g_dev")]
+
+
+class UavEnvInject(C.Structure):
+    _fields_ = [(n, _P) for n in ("theta_u_dev", "group_u_dev", "fading_dev")]
+
+
+OUT_FIELDS = ("reward", "done", "mean_sinr", "n_out", "ue_xy", "bs_xy", "serving", "cur_sinr", "step_n",
+              "cur_sinr_f64", "mean_sinr_f64", "reward_f64")
+
+
+class UavEnvOut(C.Structure):
+    _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
+
+
+STATE_FIELDS = ("ue_x", "ue_y", "ue_hu", "g_x", "g_y", "g_fl", "g_v", "g_cos", "g_sin", "agg", "deagg", "tick",
+                "bs_xy", "serving", "fifo", "fifo_depth", "out_bits", "step_n", "ue_xy")
+
+
+class UavEnvStateLayout(C.Structure):
+    _fields_ = [("total_bytes", C.c_size_t)] + [(n, C.c_size_t) for n in STATE_FIELDS]
+
+
+EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_step", "uavenv_step_trace", "uavenv_obs_dense",
+           "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10")
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libuavenv.so")
+
+
+class UavEnvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libuavenv.so; raises UavEnvError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.isfile(path):
+        raise UavEnvError("libuavenv.so not built: run `python -m drl_uav_cellularnet_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.uavenv_last_error.restype = C.c_char_p
+    lib.uavenv_abi_version.restype = C.c_int
+    lib.uavenv_default_config.argtypes = [C.POINTER(UavEnvConfig), C.c_int, C.c_int, C.c_int]
+    lib.uavenv_create.argtypes = [C.POINTER(UavEnvConfig), C.c_int64, C.c_int, C.c_uint64, C.c_uint32,
+                                  C.POINTER(_P)]
+    lib.uavenv_destroy.argtypes = [_P]
+    lib.uavenv_destroy.restype = None
+    lib.uavenv_init.argtypes = [_P, C.POINTER(UavEnvInitInject), _P]
+    lib.uavenv_warmup.argtypes = [_P, C.c_int, C.POINTER(UavEnvInject), _P]
+    lib.uavenv_reset.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_obs_dense.argtypes = [_P, _P, _P]
+    lib.uavenv_state_layout.argtypes = [_P, C.POINTER(UavEnvStateLayout)]
+    lib.uavenv_get_state.argtypes = [_P, _P, C.c_int, _P]
+    lib.uavenv_set_state.argtypes = [_P, _P, C.c_int, _P]
+    lib.uavenv_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.uavenv_philox4x32_10.restype = None
+    if lib.uavenv_abi_version() != 1:
+        raise UavEnvError("libuavenv.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise UavEnvError("libuavenv error %d: %s" % (rc, load().uavenv_last_error().decode()))
+
+
+def make_config(n_bs, n_ue, grid, groups=None, bs_init=None, **over):
+    cfg = UavEnvConfig()
+    check(load().uavenv_default_config(C.byref(cfg), int(n_bs), int(n_ue), int(grid)))
+    if groups is not None:
+        groups = [int(g) for g in groups]
+        if sum(groups) != n_ue or len(groups) > MAX_GROUPS:
+            raise ValueError("groups must sum to n_ue and number at most %d" % MAX_GROUPS)
+        cfg.n_groups = len(groups)
+        for i in range(MAX_GROUPS):
+            cfg.group_size[i] = groups[i] if i < len(groups) else 0
+    if bs_init is not None:
+        for b in range(n_bs):
+            cfg.bs_init_xy[b][0] = int(bs_init[b][0])
+            cfg.bs_init_xy[b][1] = int(bs_init[b][1])
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError("UavEnvConfig has no field %r" % k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(v) for v in ctr])
+    k = (C.c_uint32 * 2)(*[int(v) for v in key])
+    o = (C.c_uint32 * 4)()
+    load().uavenv_philox4x32_10(c, k, o)
+    return [int(v) for v in o]

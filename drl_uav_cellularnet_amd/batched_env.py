@@ -1,0 +1,258 @@
+"""BatchedMobiEnv: N independent UAV-cellular environments stepped by one HIP kernel launch.
+
+Host-side mirror of the reference's ``MobiEnvironment`` (mobile_env.py:35-194) for a batch:
+same constructor meaning (nBS, nUE, grid_n), same ``reset()`` / ``step(action)`` /
+``step_test(action)`` semantics per env, tensors instead of scalars.  PyTorch is plumbing only
+(device memory + streams); all computation happens in libuavenv.so (csrc/uavenv_kernels.h).
+
+    env = BatchedMobiEnv(4096, nBS=4, nUE=20, grid_n=100)       # ctor = init + 200 warm-up ticks + reset
+    obs = env.reset()                                          # compact obs: dict of device tensors
+    obs, reward, done, info = env.step(actions)                # actions: int64 [N] in [0, 5**nBS)
+    dense = env.dense_obs()                                    # (N, nBS+1, G, G) float32, reference layout
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import UavEnvError  # noqa: F401  (re-export)
+
+_OUT_SPECS = {
+    # name: (dtype, shape-builder)
+    "reward": (torch.float32, lambda N, U, B: (N,)),
+    "done": (torch.uint8, lambda N, U, B: (N,)),
+    "mean_sinr": (torch.float32, lambda N, U, B: (N,)),
+    "n_out": (torch.int32, lambda N, U, B: (N,)),
+    "ue_xy": (torch.int16, lambda N, U, B: (N, U, 2)),
+    "bs_xy": (torch.int32, lambda N, U, B: (N, B, 2)),
+    "serving": (torch.int8, lambda N, U, B: (N, U)),
+    "cur_sinr": (torch.float32, lambda N, U, B: (N, U)),
+    "step_n": (torch.int32, lambda N, U, B: (N,)),
+    "cur_sinr_f64": (torch.float64, lambda N, U, B: (N, U)),
+    "mean_sinr_f64": (torch.float64, lambda N, U, B: (N,)),
+    "reward_f64": (torch.float64, lambda N, U, B: (N,)),
+}
+
+_STATE_DTYPES = {
+    "ue_x": np.float64, "ue_y": np.float64, "ue_hu": np.float64, "g_x": np.float64, "g_y": np.float64,
+    "g_fl": np.float64, "g_v": np.float64, "g_cos": np.float64, "g_sin": np.float64, "agg": np.int32,
+    "deagg": np.int32, "tick": np.uint32, "bs_xy": np.int32, "serving": np.int8, "fifo": np.int8,
+    "fifo_depth": np.int32, "out_bits": np.uint64, "step_n": np.int32, "ue_xy": np.int16,
+}
+
+
+class BatchedMobiEnv:
+    N_ACT = 5  # mobile_env.py:21
+    WARMUP_TICKS = 200  # mobile_env.py:77-79
+
+    def __init__(self, n_envs, nBS=4, nUE=20, grid_n=100, groups=None, bs_init=None, device=None, seed=0x5EED,
+                 env_id_base=0, f64_outputs=False, construct=True, _cfg=None, **config_overrides):
+        if not torch.cuda.is_available():
+            raise UavEnvError("BatchedMobiEnv needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self._lib = _capi.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise UavEnvError("device must be a cuda/HIP device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_envs, self.nBS, self.nUE, self.grid_n = int(n_envs), int(nBS), int(nUE), int(grid_n)
+        self.seed, self.env_id_base = int(seed), int(env_id_base)
+        self.cfg = _cfg if _cfg is not None else _capi.make_config(nBS, nUE, grid_n, groups=groups, bs_init=bs_init,
+                                                                   **config_overrides)
+        self.n_groups = int(self.cfg.n_groups)
+        self.action_space_dim = self.N_ACT ** self.nBS                      # mobile_env.py:104
+        self.observation_space_dim = self.grid_n * self.grid_n * (self.nBS + 1)  # mobile_env.py:105
+        self._h = C.c_void_p()
+        _capi.check(self._lib.uavenv_create(C.byref(self.cfg), self.n_envs, self.device.index, self.seed,
+                                            self.env_id_base, C.byref(self._h)))
+        N, U, B = self.n_envs, self.nUE, self.nBS
+        self.out = {}
+        self._out_struct = _capi.UavEnvOut()
+        for name, (dt, shp) in _OUT_SPECS.items():
+            if name.endswith("_f64") and not f64_outputs:
+                continue
+            t = torch.zeros(shp(N, U, B), dtype=dt, device=self.device)
+            self.out[name] = t
+            setattr(self._out_struct, name + "_dev", t.data_ptr())
+        self._out_ref = C.byref(self._out_struct)
+        self._lay = _capi.UavEnvStateLayout()
+        _capi.check(self._lib.uavenv_state_layout(self._h, C.byref(self._lay)))
+        self._keep = None
+        self._constructed = False
+        if construct:
+            self.construct()
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.uavenv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- injected randomness (parity tests) --------------------------------------------------------
+    def _dev64(self, a, shape):
+        t = torch.as_tensor(a, dtype=torch.float64).reshape(shape)
+        return t.to(self.device).contiguous()
+
+    def _inject(self, theta_u=None, group_u=None, fading=None):
+        if theta_u is None and group_u is None and fading is None:
+            return None
+        N, U, B, Gr = self.n_envs, self.nUE, self.nBS, self.n_groups
+        inj = _capi.UavEnvInject()
+        keep = []
+        for name, a, shape in (("theta_u_dev", theta_u, (N, U)), ("group_u_dev", group_u, (N, Gr, 3)),
+                               ("fading_dev", fading, (N, U, B))):
+            if a is not None:
+                t = self._dev64(a, shape)
+                keep.append(t)
+                setattr(inj, name, t.data_ptr())
+        self._keep = keep  # stream-ordered use: keep alive until the next call
+        return C.byref(inj)
+
+    # ---- constructor pieces (mobile_env.py:76-98) ----------------------------------------------------
+    def init(self, u_x=None, u_y=None, u_th=None, u_g=None):
+        """reference_point_group state construction (ue_mobility.py:433-451)."""
+        inj = None
+        if u_x is not None:
+            N, U, Gr = self.n_envs, self.nUE, self.n_groups
+            ts = [self._dev64(u_x, (N, U)), self._dev64(u_y, (N, U)), self._dev64(u_th, (N, U)),
+                  self._dev64(u_g, (N, 5, Gr))]
+            ii = _capi.UavEnvInitInject()
+            ii.u_x_dev, ii.u_y_dev, ii.u_th_dev, ii.u_g_dev = (t.data_ptr() for t in ts)
+            self._keep = ts
+            inj = C.byref(ii)
+        _capi.check(self._lib.uavenv_init(self._h, inj, self._stream()))
+
+    def warmup(self, n_ticks=1, theta_u=None, group_u=None):
+        """n_ticks x next(self.mm) with no channel update (mobile_env.py:77-79)."""
+        _capi.check(self._lib.uavenv_warmup(self._h, int(n_ticks), self._inject(theta_u, group_u), self._stream()))
+
+    def construct(self):
+        """Everything MobiEnvironment.__init__ does: initial draws, 200 warm-up ticks, then the 201st tick +
+        LTEChannel.__init__, which is exactly reset() with the UAVs already on their start cells."""
+        self.init()
+        self.warmup(self.WARMUP_TICKS)
+        self._constructed = True
+        return self.reset()
+
+    # ---- gym-style API -----------------------------------------------------------------------------
+    def reset(self, mask=None, theta_u=None, group_u=None, fading=None):
+        """MobiEnvironment.reset (mobile_env.py:115-148) for every env, or those with mask[e] != 0."""
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.n_envs:
+                raise ValueError("mask must have n_envs elements")
+            self._mask_keep = mask
+            mptr = mask.data_ptr()
+        _capi.check(self._lib.uavenv_reset(self._h, mptr, self._inject(theta_u, group_u, fading), self._out_ref,
+                                           self._stream()))
+        return self.observation()
+
+    def step(self, actions, theta_u=None, group_u=None, fading=None):
+        """MobiEnvironment.step (mobile_env.py:150-194): returns (obs, reward, done, info).
+
+        ``actions``: int64 tensor [N] on this device, each in [0, 5**nBS) (base-5 digits, most significant
+        digit -> UAV 0, ue_mobility.py:310-336).  Outputs are persistent device tensors, overwritten by the
+        next call (copy what must survive).  No auto-reset, as in the reference."""
+        a = self._actions(actions)
+        inj = None if (theta_u is None and group_u is None and fading is None) else self._inject(theta_u, group_u,
+                                                                                                 fading)
+        rc = self._lib.uavenv_step(self._h, a.data_ptr(), inj, self._out_ref, self._stream())
+        if rc:
+            _capi.check(rc)
+        o = self.out
+        return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
+                                                             "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
+
+    def step_trace(self, actions, ue_xy, fading=None):
+        """MobiEnvironment.step_test with mobility_model == 'read_trace' (mobile_env.py:196-233)."""
+        a = self._actions(actions)
+        x = torch.as_tensor(ue_xy).to(device=self.device, dtype=torch.int16).contiguous()
+        if x.numel() != self.n_envs * self.nUE * 2:
+            raise ValueError("ue_xy must be [N, U, 2]")
+        self._trace_keep = x
+        _capi.check(self._lib.uavenv_step_trace(self._h, a.data_ptr(), x.data_ptr(), self._inject(None, None, fading),
+                                                self._out_ref, self._stream()))
+        o = self.out
+        return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
+                                                             "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
+
+    def _actions(self, actions):
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device
+                and a.is_contiguous()):
+            a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int64).contiguous()
+            self._act_keep = a
+        if a.numel() != self.n_envs:
+            raise ValueError("actions must have n_envs elements")
+        return a
+
+    def observation(self):
+        """Compact observation: the ~(U+B) non-zero cells of the reference's state tensor."""
+        o = self.out
+        return {"ue_xy": o["ue_xy"], "bs_xy": o["bs_xy"], "serving": o["serving"]}
+
+    def dense_obs(self, out=None):
+        """env.state for every env: float32 [N, nBS+1, G, G] (plane 0 = UAV cells, plane 1+b = UEs served by b)."""
+        N, B, G = self.n_envs, self.nBS, self.grid_n
+        if out is None:
+            out = torch.empty((N, B + 1, G, G), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.numel() != N * (B + 1) * G * G or not out.is_contiguous():
+            raise ValueError("out must be contiguous float32 [N, nBS+1, G, G]")
+        _capi.check(self._lib.uavenv_obs_dense(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    # ---- state blob: copy.deepcopy(env) (gradient.py:15) / checkpoint --------------------------------
+    def get_state(self):
+        """Whole persistent state as one host uint8 array (synchronises)."""
+        buf = np.empty(self._lay.total_bytes, np.uint8)
+        _capi.check(self._lib.uavenv_get_state(self._h, buf.ctypes.data, 0, self._stream()))
+        return buf
+
+    def set_state(self, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        if blob.size != self._lay.total_bytes:
+            raise ValueError("state blob has the wrong size")
+        _capi.check(self._lib.uavenv_set_state(self._h, blob.ctypes.data, 0, self._stream()))
+
+    def state_fields(self, blob=None):
+        """Named numpy views into a state blob (see UavEnvStateLayout in include/uavenv.h)."""
+        blob = self.get_state() if blob is None else blob
+        N, U, B, Gr = self.n_envs, self.nUE, self.nBS, self.n_groups
+        W64 = (U + 63) // 64
+        shapes = {"ue_x": (N, U), "ue_y": (N, U), "ue_hu": (N, U), "g_x": (N, Gr), "g_y": (N, Gr), "g_fl": (N, Gr),
+                  "g_v": (N, Gr), "g_cos": (N, Gr), "g_sin": (N, Gr), "agg": (N,), "deagg": (N,), "tick": (N,),
+                  "bs_xy": (N, B, 2), "serving": (N, U), "fifo": (N, 3, U), "fifo_depth": (N,),
+                  "out_bits": (N, W64), "step_n": (N,), "ue_xy": (N, U, 2)}
+        views = {}
+        for name, shp in shapes.items():
+            dt = np.dtype(_STATE_DTYPES[name])
+            off = getattr(self._lay, name)
+            n = int(np.prod(shp))
+            views[name] = blob[off:off + n * dt.itemsize].view(dt).reshape(shp)
+        return views
+
+    def clone(self):
+        """Independent copy (same config, seed and state), as copy.deepcopy(env) gives in the reference."""
+        other = BatchedMobiEnv.__new__(BatchedMobiEnv)
+        BatchedMobiEnv.__init__(other, self.n_envs, self.nBS, self.nUE, self.grid_n, device=self.device,
+                                seed=self.seed, env_id_base=self.env_id_base,
+                                f64_outputs="cur_sinr_f64" in self.out, construct=False, _cfg=self.cfg)
+        tmp = torch.empty(self._lay.total_bytes, dtype=torch.uint8, device=self.device)
+        _capi.check(self._lib.uavenv_get_state(self._h, tmp.data_ptr(), 1, self._stream()))
+        _capi.check(other._lib.uavenv_set_state(other._h, tmp.data_ptr(), 1, self._stream()))
+        for k, v in self.out.items():
+            other.out[k].copy_(v)
+        other._constructed = self._constructed
+        torch.cuda.current_stream(self.device).synchronize()
+        return other

@@ -1,0 +1,40 @@
+// Philox4x32-10 counter-based generator (Salmon, Moraes, Dror, Shaw, SC'11), host + gfx950 device.
+// Replaces the reference's process-global MT19937 draws (ue_mobility.py:6,408,508; channel.py:240):
+// one independent stream per (env, tick, index, draw site), so results do not depend on scheduling.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define UAVENV_HD __host__ __device__ __forceinline__
+#else
+#define UAVENV_HD inline
+#endif
+
+namespace uavk {
+
+enum DrawSite : uint32_t {  // Philox counter word 3
+    DOM_FADING = 1, DOM_HEADING = 2, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
+    DOM_INIT_UE_A = 5, DOM_INIT_UE_B = 6, DOM_INIT_G_A = 7, DOM_INIT_G_B = 8, DOM_INIT_G_C = 9
+};
+
+struct U4 { uint32_t x, y, z, w; };
+
+UAVENV_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// 53-bit uniform in [0,1) from two words
+UAVENV_HD double u53(uint32_t hi, uint32_t lo) {
+    return (double)(((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace uavk

@@ -1,0 +1,319 @@
+// C ABI of libuavenv (include/uavenv.h): handle management, state blob, kernel dispatch.
+// gfx950 only; built by drl_uav_cellularnet_amd/build.py with hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/uavenv.h"
+#include "uavenv_kernels.h"
+
+using namespace uavk;
+
+static_assert(UAVENV_MAX_GROUPS == kMaxGroups && UAVENV_MAX_BS == kMaxBs, "header / kernel bounds differ");
+
+struct uavenv {
+    UavEnvConfig cfg;
+    long long N;
+    int device;
+    uint64_t seed;
+    uint32_t env_id_base;
+    int bt;  // template bound on B
+    char *blob;
+    int32_t *bs_init_dev;
+    UavEnvStateLayout lay;
+    KParams kp;  // constants + state pointers, per-call fields patched at launch
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(UAVENV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+// Launches go to the handle's device whatever the caller's current device is; restored on return.
+struct DeviceGuard {
+    int prev = -1, want;
+    explicit DeviceGuard(int dev) : want(dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" int uavenv_abi_version(void) { return UAVENV_ABI_VERSION; }
+extern "C" const char *uavenv_last_error(void) { return g_err.c_str(); }
+
+extern "C" void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const U4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+extern "C" int uavenv_default_config(UavEnvConfig *c, int n_bs, int n_ue, int grid) {
+    if (!c || n_bs < 1 || n_bs > UAVENV_MAX_BS || n_ue < 1 || grid < 8)
+        return fail(UAVENV_E_INVALID, "default_config: bad n_bs/n_ue/grid");
+    std::memset(c, 0, sizeof(*c));
+    c->n_bs = n_bs; c->n_ue = n_ue; c->grid = grid;
+    c->n_groups = 4;  // mobile_env.py:76: four groups
+    int left = n_ue;
+    for (int g = 0; g < 4; ++g) { c->group_size[g] = (g < 3) ? n_ue / 4 : left; left -= c->group_size[g]; }
+    if (n_bs == 4) {  // mobile_env.py:49-50
+        const int q = grid / 4, t = grid * 3 / 4;
+        const int xs[4] = {q, q, t, t}, ys[4] = {q, t, q, t};
+        for (int b = 0; b < 4; ++b) { c->bs_init_xy[b][0] = xs[b]; c->bs_init_xy[b][1] = ys[b]; }
+    } else {  // the reference ctor cannot build n_bs != 4: square lattice, caller may override
+        int side = 1;
+        while (side * side < n_bs) ++side;
+        for (int b = 0; b < n_bs; ++b) {
+            c->bs_init_xy[b][0] = grid / (2 * side) + (b / side) * (grid / side);
+            c->bs_init_xy[b][1] = grid / (2 * side) + (b % side) * (grid / side);
+        }
+    }
+    c->max_step = 2000; c->bs_step = 2; c->min_bs_dist = 4; c->n_act = 5;
+    c->agg_init = 200; c->deagg_len = 100; c->agg_len = 10;
+    c->grid_width = 5.0; c->p_bs_dbm = 20.0; c->noise_dbm = -121.0;
+    c->pl_a = 38.0; c->pl_b = 30.0; c->pl_dis = 0.0; c->antenna_gain = 2.0; c->eq_loss = 0.0;
+    c->shadow_mean = 0.0; c->shadow_sd = 2.0; c->ho_thresh_db = 1.0; c->out_thresh = 0.0;
+    c->ue_velocity = 1.0; c->grp_v_min = 0.0; c->grp_v_max = 1.0; c->aggregation = 0.8;
+    return UAVENV_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int check_config(const UavEnvConfig &c) {
+    if (c.n_bs < 1 || c.n_bs > UAVENV_MAX_BS) return fail(UAVENV_E_INVALID, "config: n_bs out of range [1,32]");
+    if (c.n_ue < 1 || c.n_ue > 4096) return fail(UAVENV_E_INVALID, "config: n_ue out of range [1,4096]");
+    if (c.n_groups < 1 || c.n_groups > UAVENV_MAX_GROUPS) return fail(UAVENV_E_INVALID, "config: n_groups out of range");
+    if (c.grid < 8 || c.grid > 32767) return fail(UAVENV_E_INVALID, "config: grid out of range [8,32767]");
+    int s = 0;
+    for (int g = 0; g < c.n_groups; ++g) {
+        if (c.group_size[g] < 0) return fail(UAVENV_E_INVALID, "config: negative group size");
+        s += c.group_size[g];
+    }
+    if (s != c.n_ue) return fail(UAVENV_E_INVALID, "config: group sizes do not sum to n_ue");
+    if (c.n_act < 2 || c.n_act > 9) return fail(UAVENV_E_INVALID, "config: n_act out of range [2,9]");
+    if (c.max_step < 1 || c.bs_step < 0 || c.min_bs_dist < 0) return fail(UAVENV_E_INVALID, "config: bad step constants");
+    for (int b = 0; b < c.n_bs; ++b)
+        if (c.bs_init_xy[b][0] < 0 || c.bs_init_xy[b][0] >= c.grid || c.bs_init_xy[b][1] < 0 || c.bs_init_xy[b][1] >= c.grid)
+            return fail(UAVENV_E_INVALID, "config: UAV start cell outside the grid");
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device, uint64_t seed, uint32_t env_id_base,
+                             uavenv_t **out) {
+    if (!cfg || !out || n_envs < 1) return fail(UAVENV_E_INVALID, "create: null argument or n_envs < 1");
+    if (int rc = check_config(*cfg)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || device < 0 || device >= n_dev)
+        return fail(UAVENV_E_NODEVICE, "create: no HIP device " + std::to_string(device));
+    HIP_TRY(hipSetDevice(device));
+    uavenv *h = new (std::nothrow) uavenv();
+    if (!h) return fail(UAVENV_E_NOMEM, "create: host allocation failed");
+    h->cfg = *cfg; h->N = n_envs; h->device = device; h->seed = seed; h->env_id_base = env_id_base;
+    const size_t N = (size_t)n_envs, U = (size_t)cfg->n_ue, B = (size_t)cfg->n_bs, Gr = (size_t)cfg->n_groups;
+    const size_t W64 = (U + 63) / 64;
+    h->bt = B <= 4 ? 4 : B <= 8 ? 8 : B <= 16 ? 16 : 32;
+
+    UavEnvStateLayout &L = h->lay;
+    size_t off = 0;
+    auto put = [&](size_t &field, size_t bytes) { field = off; off = align_up(off + bytes, 256); };
+    put(L.ue_x, N * U * 8); put(L.ue_y, N * U * 8); put(L.ue_hu, N * U * 8);
+    put(L.g_x, N * Gr * 8); put(L.g_y, N * Gr * 8); put(L.g_fl, N * Gr * 8);
+    put(L.g_v, N * Gr * 8); put(L.g_cos, N * Gr * 8); put(L.g_sin, N * Gr * 8);
+    put(L.agg, N * 4); put(L.deagg, N * 4); put(L.tick, N * 4);
+    put(L.bs_xy, N * B * 2 * 4); put(L.serving, N * U); put(L.fifo, N * 3 * U); put(L.fifo_depth, N * 4);
+    put(L.out_bits, N * W64 * 8); put(L.step_n, N * 4); put(L.ue_xy, N * U * 2 * 2);
+    L.total_bytes = off;
+
+    hipError_t e = hipMalloc((void **)&h->blob, L.total_bytes);
+    if (e != hipSuccess) { delete h; return fail(UAVENV_E_NOMEM, std::string("create: hipMalloc state: ") + hipGetErrorString(e)); }
+    e = hipMalloc((void **)&h->bs_init_dev, sizeof(int32_t) * 2 * UAVENV_MAX_BS);
+    if (e != hipSuccess) { (void)hipFree(h->blob); delete h; return fail(UAVENV_E_NOMEM, "create: hipMalloc bs_init"); }
+    (void)hipMemset(h->blob, 0, L.total_bytes);
+    (void)hipMemcpy(h->bs_init_dev, cfg->bs_init_xy, sizeof(int32_t) * 2 * UAVENV_MAX_BS, hipMemcpyHostToDevice);
+
+    KParams &k = h->kp;
+    std::memset(&k, 0, sizeof(k));
+    k.U = cfg->n_ue; k.B = cfg->n_bs; k.Gr = cfg->n_groups; k.G = cfg->grid; k.W64 = (int)W64;
+    int acc = 0;
+    for (int g = 0; g <= kMaxGroups; ++g) {
+        k.group_start[g] = acc;
+        if (g < cfg->n_groups) acc += cfg->group_size[g];
+    }
+    k.max_step = cfg->max_step; k.bs_step = cfg->bs_step; k.min_bs_dist2 = cfg->min_bs_dist * cfg->min_bs_dist;
+    k.n_act = cfg->n_act; k.agg_init = cfg->agg_init; k.deagg_len = cfg->deagg_len; k.agg_len = cfg->agg_len;
+    k.grid_width = cfg->grid_width;
+    k.p_bs_watt = std::pow(10.0, cfg->p_bs_dbm / 10.0) * 1e-3;    // channel.py:58
+    k.noise_watt = std::pow(10.0, cfg->noise_dbm / 10.0) * 1e-3;  // channel.py:59
+    k.pl_a = cfg->pl_a; k.pl_b = cfg->pl_b; k.pl_dis = cfg->pl_dis; k.antenna_gain = cfg->antenna_gain;
+    k.eq_loss = cfg->eq_loss; k.shadow_mean = cfg->shadow_mean; k.shadow_sd = cfg->shadow_sd;
+    k.ho_thresh_db = cfg->ho_thresh_db; k.out_thresh = cfg->out_thresh; k.ue_velocity = cfg->ue_velocity;
+    k.grp_v_min = cfg->grp_v_min; k.grp_v_max = cfg->grp_v_max; k.aggregation = cfg->aggregation;
+    k.N = n_envs; k.key0 = (uint32_t)seed; k.key1 = (uint32_t)(seed >> 32); k.env_id_base = env_id_base;
+    char *b = h->blob;
+    k.ue_x = (double *)(b + L.ue_x); k.ue_y = (double *)(b + L.ue_y); k.ue_hu = (double *)(b + L.ue_hu);
+    k.g_x = (double *)(b + L.g_x); k.g_y = (double *)(b + L.g_y); k.g_fl = (double *)(b + L.g_fl);
+    k.g_v = (double *)(b + L.g_v); k.g_cos = (double *)(b + L.g_cos); k.g_sin = (double *)(b + L.g_sin);
+    k.agg = (int32_t *)(b + L.agg); k.deagg = (int32_t *)(b + L.deagg); k.tick = (uint32_t *)(b + L.tick);
+    k.bs_xy = (int32_t *)(b + L.bs_xy); k.serving = (int8_t *)(b + L.serving); k.fifo = (int8_t *)(b + L.fifo);
+    k.fifo_depth = (int32_t *)(b + L.fifo_depth); k.out_bits = (unsigned long long *)(b + L.out_bits);
+    k.step_n = (int32_t *)(b + L.step_n); k.ue_xy = (int16_t *)(b + L.ue_xy);
+    k.bs_init = h->bs_init_dev;
+    *out = h;
+    return UAVENV_OK;
+}
+
+extern "C" void uavenv_destroy(uavenv_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->blob);
+    (void)hipFree(h->bs_init_dev);
+    delete h;
+}
+
+extern "C" int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *stream) {
+    if (!h) return fail(UAVENV_E_INVALID, "init: null handle");
+    if (inj && (!inj->u_x_dev || !inj->u_y_dev || !inj->u_th_dev || !inj->u_g_dev))
+        return fail(UAVENV_E_INVALID, "init: injection needs all four arrays");
+    DeviceGuard guard(h->device);
+    const KParams &k = h->kp;
+    InitParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.U = k.U; p.Gr = k.Gr; p.B = k.B; p.W64 = k.W64; p.G = k.G; p.agg_init = k.agg_init; p.deagg_len = k.deagg_len;
+    p.grp_v_min = k.grp_v_min; p.grp_v_max = k.grp_v_max; p.N = k.N; p.key0 = k.key0; p.key1 = k.key1;
+    p.env_id_base = k.env_id_base;
+    p.ue_x = k.ue_x; p.ue_y = k.ue_y; p.ue_hu = k.ue_hu; p.g_x = k.g_x; p.g_y = k.g_y; p.g_fl = k.g_fl; p.g_v = k.g_v;
+    p.g_cos = k.g_cos; p.g_sin = k.g_sin; p.agg = k.agg; p.deagg = k.deagg; p.tick = k.tick; p.bs_xy = k.bs_xy;
+    p.serving = k.serving; p.fifo = k.fifo; p.fifo_depth = k.fifo_depth; p.out_bits = k.out_bits; p.step_n = k.step_n;
+    p.ue_xy = k.ue_xy; p.bs_init = k.bs_init;
+    if (inj) { p.u_x = inj->u_x_dev; p.u_y = inj->u_y_dev; p.u_th = inj->u_th_dev; p.u_g = inj->u_g_dev; }
+    p.per = k.U;
+    if (k.Gr > p.per) p.per = k.Gr;
+    if (k.B > p.per) p.per = k.B;
+    if (k.W64 > p.per) p.per = k.W64;
+    const long long total = k.N * p.per;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(init_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+template <int MODE>
+static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
+    const unsigned grid = (unsigned)((p.N + kWavesPerBlock - 1) / kWavesPerBlock);
+    const dim3 blk(64 * kWavesPerBlock);
+    switch (h->bt) {
+        case 4: hipLaunchKernelGGL((env_kernel<4, MODE>), dim3(grid), blk, 0, s, p); break;
+        case 8: hipLaunchKernelGGL((env_kernel<8, MODE>), dim3(grid), blk, 0, s, p); break;
+        case 16: hipLaunchKernelGGL((env_kernel<16, MODE>), dim3(grid), blk, 0, s, p); break;
+        default: hipLaunchKernelGGL((env_kernel<32, MODE>), dim3(grid), blk, 0, s, p); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+static void fill_call(KParams &p, const UavEnvInject *inj, const UavEnvOut *out) {
+    p.inj_theta = inj ? inj->theta_u_dev : nullptr;
+    p.inj_group = inj ? inj->group_u_dev : nullptr;
+    p.inj_fading = inj ? inj->fading_dev : nullptr;
+    std::memset(&p.out, 0, sizeof(p.out));
+    if (out) {
+        p.out.reward = out->reward_dev; p.out.done = out->done_dev; p.out.mean_sinr = out->mean_sinr_dev;
+        p.out.n_out = out->n_out_dev; p.out.ue_xy = out->ue_xy_dev; p.out.bs_xy = out->bs_xy_dev;
+        p.out.serving = out->serving_dev; p.out.cur_sinr = out->cur_sinr_dev; p.out.step_n = out->step_n_dev;
+        p.out.cur_sinr_f64 = out->cur_sinr_f64_dev; p.out.mean_sinr_f64 = out->mean_sinr_f64_dev;
+        p.out.reward_f64 = out->reward_f64_dev;
+    }
+}
+
+extern "C" int uavenv_warmup(uavenv_t *h, int n_ticks, const UavEnvInject *inj, void *stream) {
+    if (!h || n_ticks < 0) return fail(UAVENV_E_INVALID, "warmup: null handle or negative n_ticks");
+    if (n_ticks == 0) return UAVENV_OK;
+    if (inj && (inj->theta_u_dev || inj->group_u_dev) && n_ticks != 1)
+        return fail(UAVENV_E_INVALID, "warmup: injected draws cover exactly one tick");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, inj, nullptr);
+    p.n_ticks = n_ticks;
+    return launch_env<MODE_WARMUP>(h, p, (hipStream_t)stream);
+}
+
+extern "C" int uavenv_reset(uavenv_t *h, const uint8_t *mask_dev, const UavEnvInject *inj, const UavEnvOut *out,
+                            void *stream) {
+    if (!h) return fail(UAVENV_E_INVALID, "reset: null handle");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, inj, out);
+    p.mask = mask_dev; p.n_ticks = 1;
+    return launch_env<MODE_RESET>(h, p, (hipStream_t)stream);
+}
+
+extern "C" int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj, const UavEnvOut *out,
+                           void *stream) {
+    if (!h || !actions_dev) return fail(UAVENV_E_INVALID, "step: null handle or actions");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, inj, out);
+    p.actions = (const long long *)actions_dev; p.n_ticks = 1;
+    return launch_env<MODE_STEP>(h, p, (hipStream_t)stream);
+}
+
+extern "C" int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
+                                 const UavEnvInject *inj, const UavEnvOut *out, void *stream) {
+    if (!h || !actions_dev || !ue_xy_in_dev) return fail(UAVENV_E_INVALID, "step_trace: null handle, actions or trace");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, inj, out);
+    p.actions = (const long long *)actions_dev; p.trace_xy = ue_xy_in_dev; p.n_ticks = 1;
+    return launch_env<MODE_TRACE>(h, p, (hipStream_t)stream);
+}
+
+extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense: null handle or buffer");
+    DeviceGuard guard(h->device);
+    const KParams &k = h->kp;
+    const size_t bytes = (size_t)k.N * (k.B + 1) * k.G * k.G * sizeof(float);
+    HIP_TRY(hipMemsetAsync(obs_dev, 0, bytes, (hipStream_t)stream));
+    const long long total = k.N * (k.U + k.B);
+    hipLaunchKernelGGL(obs_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k.N,
+                       k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, obs_dev);
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout) {
+    if (!h || !layout) return fail(UAVENV_E_INVALID, "state_layout: null argument");
+    *layout = h->lay;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_get_state(uavenv_t *h, void *dst, int dst_is_device, void *stream) {
+    if (!h || !dst) return fail(UAVENV_E_INVALID, "get_state: null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(dst, h->blob, h->lay.total_bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+    if (!dst_is_device) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_state(uavenv_t *h, const void *src, int src_is_device, void *stream) {
+    if (!h || !src) return fail(UAVENV_E_INVALID, "set_state: null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(h->blob, src, h->lay.total_bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+    if (!src_is_device) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return UAVENV_OK;
+}

@@ -1,0 +1,475 @@
+// HIP kernels of the batched UAV-cellular environment for gfx950 (MI355X / CDNA4).
+//
+// Mapping: ONE WAVEFRONT (64 lanes) PER ENV INSTANCE; 4 envs per 256-thread workgroup.
+//   lane  -> UE (u = lane + 64*pass; 20/40 UEs: one pass, 200 UEs: four passes)
+//   lanes 0..Gr-1 also own one RPGM group each, lanes 0..B-1 one UAV each
+//   UAV cells are staged in LDS (one row per wave) and read back as broadcasts in the per-UE
+//   path-loss loop; gains / SINRs of the BT base stations live in registers (BT = template bound
+//   on B so every index is static); mean SINR, outage set and outage count are wavefront
+//   reductions (shuffles / ballots).  No MFMA: there is no dense contraction on this path.
+//   All arithmetic is float64 (float32 breaks the 1e-5 relative bound near 0 dB
+//   and can flip handover / outage decisions); outputs are rounded to float32 once.
+//
+// What the code follows in the reference (/root/reference):
+//   mobility tick      ue_mobility.py:453-523     UAV move   ue_mobility.py:191-271,310-336
+//   gains, DL SINR     channel.py:220-269         handover / outage / mean   channel.py:138-216
+//   reset              channel.py:113-124, mobile_env.py:115-148      reward  mobile_env.py:163-189
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.h"
+
+namespace uavk {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxGroups = 16;
+constexpr int kMaxBs = 32;
+
+enum Mode : int { MODE_WARMUP = 0, MODE_RESET = 1, MODE_STEP = 2, MODE_TRACE = 3 };
+
+struct OutPtrs {
+    float *reward; uint8_t *done; float *mean_sinr; int32_t *n_out;
+    int16_t *ue_xy; int32_t *bs_xy; int8_t *serving; float *cur_sinr; int32_t *step_n;
+    double *cur_sinr_f64, *mean_sinr_f64, *reward_f64;
+};
+
+struct KParams {
+    // shape / constants
+    int U, B, Gr, G, W64;
+    int group_start[kMaxGroups + 1];
+    int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
+    double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
+    double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
+    long long N;
+    uint32_t key0, key1, env_id_base;
+    // persistent state (SoA, [field][env][...])
+    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
+    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
+    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
+    const int32_t *bs_init;  // [B,2] device copy of the start cells
+    // per-call inputs
+    const double *inj_theta, *inj_group, *inj_fading;
+    const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
+    OutPtrs out;
+};
+
+struct InitParams {
+    int U, Gr, B, W64, G, per; int agg_init, deagg_len;
+    double grp_v_min, grp_v_max;
+    long long N; uint32_t key0, key1, env_id_base;
+    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
+    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
+    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy; const int32_t *bs_init;
+    const double *u_x, *u_y, *u_th, *u_g;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void philox_u2(const KParams &p, uint32_t env, uint32_t tick, uint32_t idx, uint32_t dom,
+                                          double &u0, double &u1) {
+    const U4 r = philox4x32_10(p.env_id_base + env, tick, idx, dom, p.key0, p.key1);
+    u0 = u53(r.x, r.y);
+    u1 = u53(r.z, r.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// state construction: ue_mobility.py:433-451 + mobile_env.py:58-59.  One thread per (env, walker).
+__global__ __launch_bounds__(256) void init_kernel(InitParams p) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int U = p.U, Gr = p.Gr, per = p.per;  // per = max(U, Gr, B, W64) threads per env
+    if (tid >= p.N * per) return;
+    const long long e = tid / per;
+    const int u = (int)(tid - e * per);
+    const double MAXC = (double)p.G;
+    const double two_pi = 2.0 * 3.141592653589793;
+    if (u < U) {
+        const long long t = e * U + u;
+        double ux, uy, ut;
+        if (p.u_x) { ux = p.u_x[t]; uy = p.u_y[t]; ut = p.u_th[t]; }
+        else {
+            U4 r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)u, DOM_INIT_UE_A, p.key0, p.key1);
+            ux = u53(r.x, r.y); uy = u53(r.z, r.w);
+            r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)u, DOM_INIT_UE_B, p.key0, p.key1);
+            ut = u53(r.x, r.y);
+        }
+        p.ue_x[t] = ux * MAXC;  // :434
+        p.ue_y[t] = uy * MAXC;  // :435
+        p.ue_hu[t] = ut;        // :437 (cos/sin are taken when the heading is used, :455)
+        p.serving[t] = 0;
+        p.fifo[(e * 3 + 0) * U + u] = 0; p.fifo[(e * 3 + 1) * U + u] = 0; p.fifo[(e * 3 + 2) * U + u] = 0;
+        p.ue_xy[2 * t] = 0; p.ue_xy[2 * t + 1] = 0;
+    }
+    if (u < Gr) {
+        const int g = u;
+        double v[5];
+        if (p.u_g) { for (int k = 0; k < 5; ++k) v[k] = p.u_g[(e * 5 + k) * Gr + g]; }
+        else {
+            U4 r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)g, DOM_INIT_G_A, p.key0, p.key1);
+            v[0] = u53(r.x, r.y); v[1] = u53(r.z, r.w);
+            r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)g, DOM_INIT_G_B, p.key0, p.key1);
+            v[2] = u53(r.x, r.y); v[3] = u53(r.z, r.w);
+            r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)g, DOM_INIT_G_C, p.key0, p.key1);
+            v[4] = u53(r.x, r.y);
+        }
+        p.g_x[e * Gr + g] = v[0] * MAXC;   // :442
+        p.g_y[e * Gr + g] = v[1] * MAXC;   // :443 (MAX_X, sic)
+        p.g_fl[e * Gr + g] = v[2] * MAXC;  // :444
+        p.g_v[e * Gr + g] = v[3] * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :445
+        const double th = v[4] * two_pi;   // :446
+        p.g_cos[e * Gr + g] = cos(th);
+        p.g_sin[e * Gr + g] = sin(th);
+    }
+    if (u < p.B) {
+        p.bs_xy[(e * p.B + u) * 2] = p.bs_init[2 * u];
+        p.bs_xy[(e * p.B + u) * 2 + 1] = p.bs_init[2 * u + 1];
+    }
+    if (u < p.W64) p.out_bits[e * p.W64 + u] = 0ull;
+    if (u == 0) {
+        p.agg[e] = p.agg_init; p.deagg[e] = p.deagg_len; p.tick[e] = 0u; p.fifo_depth[e] = 0; p.step_n[e] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused env kernel.  BT: compile-time bound on B (4/8/16/32).  MODE: see enum Mode.
+template <int BT, int MODE>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams p) {
+    __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
+    if (e >= p.N) return;
+    if (MODE == MODE_RESET) { if (p.mask != nullptr && p.mask[e] == 0) return; }
+
+    const int U = p.U, B = p.B, Gr = p.Gr;
+    const double MAXC = (double)p.G;
+    const int n_pass = (U + 63) >> 6;
+    const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
+
+    // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
+    if (MODE != MODE_WARMUP) {
+        int bx = 0, by = 0;
+        if (lane < B) {
+            if (MODE == MODE_RESET) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }  // mobile_env.py:119
+            else { bx = p.bs_xy[(e * B + lane) * 2]; by = p.bs_xy[(e * B + lane) * 2 + 1]; }
+        }
+        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+            long long a = p.actions[e];
+            int dig = 0;
+            for (int i = B - 1; i >= 0; --i) {  // most-significant digit -> UAV 0
+                const int d = (int)(a % p.n_act);
+                a /= p.n_act;
+                if (lane == i) dig = d;
+            }
+            const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;  // mobile_env.py:45
+            const int s = p.bs_step, sl = 2 * p.bs_step;
+            for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
+                const int xi = __shfl(bx, i, 64), yi = __shfl(by, i, 64), di = __shfl(dig, i, 64);
+                int nx = xi, ny = yi;
+                if (di == 0) { if (xi + s < xMax) nx = xi + s; }
+                else if (di == 1) { if (xi - s > xMin) nx = xi - s; }
+                else if (di == 2) { if (yi + s < yMax) ny = yi + s; }
+                else if (di == 3) { if (yi - s > yMin) ny = yi - s; }
+                else if (di == 5) { if (xi + sl < xMax) nx = xi + sl; }
+                else if (di == 6) { if (xi - sl > xMin) nx = xi - sl; }
+                else if (di == 7) { if (yi + sl < yMax) ny = yi + sl; }
+                else if (di == 8) { if (yi - sl > yMin) ny = yi - sl; }
+                // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
+                const int dx = xi - bx, dy = yi - by;
+                const bool near = (lane < B) && (lane != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
+                const bool collision = __ballot(near) != 0ull;
+                if (!collision && lane == i) { bx = nx; by = ny; }
+            }
+        }
+        if (lane < B) {
+            p.bs_xy[(e * B + lane) * 2] = bx; p.bs_xy[(e * B + lane) * 2 + 1] = by;
+            s_bs[wave][2 * lane] = bx; s_bs[wave][2 * lane + 1] = by;
+            if (p.out.bs_xy) { p.out.bs_xy[(e * B + lane) * 2] = bx; p.out.bs_xy[(e * B + lane) * 2 + 1] = by; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // per-env scalars
+    int agg = 0, deagg = 0;
+    uint32_t tick = p.tick[e];
+    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    int depth = 0, step_n = 0;
+    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+
+    double sum_cur = 0.0;
+    int n_outage = 0;
+
+    for (int it = 0; it < n_ticks; ++it) {
+        // ---- group owners: lanes 0..Gr-1 (ue_mobility.py:458-459) -----------------------------
+        double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
+        const bool aggregating = agg != 0;
+        if (MODE != MODE_TRACE) {
+            if (lane < Gr) {
+                ogx = p.g_x[e * Gr + lane]; ogy = p.g_y[e * Gr + lane]; ogfl = p.g_fl[e * Gr + lane];
+                ogv = p.g_v[e * Gr + lane]; ogc = p.g_cos[e * Gr + lane]; ogs = p.g_sin[e * Gr + lane];
+                ogx = ogx + ogv * ogc;
+                ogy = ogy + ogv * ogs;
+            }
+        }
+        uint32_t touched[4] = {0u, 0u, 0u, 0u};  // groups bounced at x<0, x>MAX, y<0, y>MAX (wave-uniform)
+
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int u = pass * 64 + lane;
+            const bool act = u < U;
+            const long long iu = e * U + (act ? u : 0);
+            int ix = 0, iy = 0;
+
+            if (MODE != MODE_TRACE) {
+                // ---- one next() of reference_point_group for walker u (ue_mobility.py:455-510) ----
+                int gid = 0;
+                for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
+                const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
+                const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
+                double x = 0, y = 0, hu = 0;
+                if (act) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
+                double sn, cs;
+                sincospi(2.0 * hu, &sn, &cs);            // theta = 2*pi*u  (:437,508)
+                x = x + p.ue_velocity * cs;               // :455
+                y = y + p.ue_velocity * sn;               // :456
+                if (aggregating) {                        // :461-470
+                    const double c = atan2(gy - y, gx - x);
+                    double sc, cc;
+                    sincos(c, &sc, &cc);
+                    x = x + gv * gc + p.aggregation * cc;
+                    y = y + gv * gs + p.aggregation * sc;
+                } else {                                  // :476-484
+                    x = x + gv * gc;
+                    y = y + gv * gs;
+                }
+                // bounce (:490-505): four ordered tests; each flips the group heading once per group
+                bool c0 = act && (x < 0.0);
+                if (c0) x = -x;
+                bool c1 = act && (x > MAXC);
+                if (c1) x = 2.0 * MAXC - x;
+                bool c2 = act && (y < 0.0);
+                if (c2) y = -y;
+                bool c3 = act && (y > MAXC);
+                if (c3) y = 2.0 * MAXC - y;
+                if (__ballot(c0 || c1 || c2 || c3) != 0ull) {  // rare, wave-uniform branch
+                    for (int g = 0; g < Gr; ++g) {
+                        const bool mine = gid == g;
+                        if (__ballot(mine && c0)) touched[0] |= 1u << g;
+                        if (__ballot(mine && c1)) touched[1] |= 1u << g;
+                        if (__ballot(mine && c2)) touched[2] |= 1u << g;
+                        if (__ballot(mine && c3)) touched[3] |= 1u << g;
+                    }
+                }
+                // new heading (:508)
+                if (p.inj_theta) { if (act) hu = p.inj_theta[iu]; }
+                else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
+                ix = (int)x; iy = (int)y;                 // .astype(int), mobile_env.py:154-155
+                if (act) {
+                    p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu;
+                    p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+                }
+            } else {
+                if (act) {                                // mobile_env.py:202-203 (read_trace)
+                    ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
+                    p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+                }
+            }
+
+            if (MODE == MODE_WARMUP) continue;
+            if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
+
+            // ---- gains + DL SINR for walker u against every UAV (channel.py:220-269) ------------
+            double pg[BT], sinr[BT];
+#pragma unroll
+            for (int b2 = 0; b2 < BT; b2 += 2) {
+                double f0 = 0.0, f1 = 0.0;
+                if (b2 < B) {
+                    if (p.inj_fading) {
+                        if (act) {
+                            f0 = p.inj_fading[iu * B + b2];
+                            if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
+                        }
+                    } else {  // np.random.normal(mean, sd) (channel.py:240): Box-Muller on Philox uniforms
+                        double u0, u1;
+                        philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
+                        const double r = sqrt(-2.0 * log(1.0 - u0));
+                        double sa, ca;
+                        sincospi(2.0 * u1, &sa, &ca);
+                        f0 = p.shadow_mean + p.shadow_sd * (r * ca);
+                        f1 = p.shadow_mean + p.shadow_sd * (r * sa);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int b = b2 + k;
+                    if (b < BT) {
+                        double g = 0.0;
+                        if (b < B) {
+                            const double fx = p.grid_width * (double)(ix - s_bs[wave][2 * b]);       // :221-222
+                            const double fy = p.grid_width * (double)(iy - s_bs[wave][2 * b + 1]);
+                            const double d = sqrt(fx * fx + fy * fy);                                 // :223 (z ignored)
+                            double loss = 0.0;                                                        // :232
+                            if (d > p.pl_dis) loss = p.pl_a + p.pl_b * log10(d);                      // :233-234
+                            const double gdb = p.antenna_gain - loss - (k == 0 ? f0 : f1) - p.eq_loss;  // :245
+                            g = exp10(gdb * 0.1);                                                     // :246
+                        }
+                        pg[b] = p.p_bs_watt * g;
+                    }
+                }
+            }
+            int best = 0;
+            double bestS = -1.0e300;
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                double interf = 0.0;  // sum over the OTHER UAVs in index order (:263-265); never total - self
+#pragma unroll
+                for (int j = 0; j < BT; ++j)
+                    if (j != b && j < B) interf += pg[j];
+                double s = -1.0e300;
+                if (b < B) s = 10.0 * log10(pg[b] / (p.noise_watt + interf));  // :266-268
+                sinr[b] = s;
+                if (s > bestS) { bestS = s; best = b; }  // np.argmax: first maximum (:141-142)
+            }
+
+            if (MODE == MODE_RESET) {
+                // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
+                const bool is_out = act && (bestS <= p.out_thresh);
+                const unsigned long long ob = __ballot(is_out);
+                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
+                if (act) {
+                    p.serving[iu] = (int8_t)best;
+                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
+                    if (p.out.serving) p.out.serving[iu] = (int8_t)best;
+                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
+                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
+                }
+                sum_cur += wave_sum(act ? bestS : 0.0);
+            } else {
+                // UpdateDroneNet, DL part (channel.py:141-174)
+                int serving = 0, r0 = 0, r1 = 0, r2 = 0;
+                if (act) {
+                    serving = p.serving[iu];
+                    r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
+                }
+                double cur = 0.0;  // SINR of the serving UAV BEFORE any handover (:145-146)
+#pragma unroll
+                for (int b = 0; b < BT; ++b) cur = (b == serving) ? sinr[b] : cur;
+                bool remain;
+                if (depth == 1) { r1 = best; remain = (r1 == r0); }                       // append (:148-149)
+                else if (depth == 2) { r2 = best; remain = (r1 == r0) && (r2 == r0); }
+                else { r0 = r1; r1 = r2; r2 = best; remain = (r1 == r0) && (r2 == r0); }  // FIFO shift (:150-153)
+                // newest row == best (:156 compares current_BS with bestBS_buf[-1])
+                const bool changed = serving != best;
+                const bool need_ho = remain && changed && (bestS - cur > p.ho_thresh_db);  // :155-159
+                if (need_ho) serving = best;                                               // :162-167
+                const bool is_out = act && (cur <= p.out_thresh);                          // :170
+                const unsigned long long ob = __ballot(is_out);
+                const unsigned long long prev = p.out_bits[e * p.W64 + pass];
+                n_outage += __popcll(ob & ~prev);                                          // :171-174 newly outaged
+                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;                          // :173
+                if (act) {
+                    p.serving[iu] = (int8_t)serving;
+                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
+                    p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
+                    p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
+                    if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
+                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
+                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
+                }
+                sum_cur += wave_sum(act ? cur : 0.0);
+            }
+        }  // passes
+
+        if (MODE != MODE_TRACE) {
+            // ---- group owners: bounce flips, flight length, arrivals (ue_mobility.py:493-521) ----
+            if (lane < Gr) {
+                const uint32_t bit = 1u << lane;
+                if (touched[0] & bit) ogc = -ogc;
+                if (touched[1] & bit) ogc = -ogc;
+                if (touched[2] & bit) ogs = -ogs;
+                if (touched[3] & bit) ogs = -ogs;
+                ogfl = ogfl - ogv;                                    // :513
+                if (ogv > 0.0 && ogfl <= 0.0) {                       // :514
+                    double ut, uf, uv, t1;
+                    if (p.inj_group) {
+                        ut = p.inj_group[(e * Gr + lane) * 3 + 0]; uf = p.inj_group[(e * Gr + lane) * 3 + 1];
+                        uv = p.inj_group[(e * Gr + lane) * 3 + 2];
+                    } else {
+                        philox_u2(p, (uint32_t)e, tick, (uint32_t)lane, DOM_GROUP_A, ut, uf);
+                        philox_u2(p, (uint32_t)e, tick, (uint32_t)lane, DOM_GROUP_B, uv, t1);
+                    }
+                    sincospi(2.0 * ut, &ogs, &ogc);                   // :517-519
+                    ogfl = uf * MAXC;                                 // :520 FL_MAX = max(dimensions)
+                    ogv = uv * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :521
+                }
+                p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;
+                p.g_v[e * Gr + lane] = ogv; p.g_cos[e * Gr + lane] = ogc; p.g_sin[e * Gr + lane] = ogs;
+            }
+            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }   // :472-473
+            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }               // :486-487
+        }
+        tick += 1u;
+        if (MODE == MODE_WARMUP && it + 1 < n_ticks) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }  // ticks
+
+    // ---- per-env scalars and outputs --------------------------------------------------------
+    if (lane == 0) {
+        p.tick[e] = tick;
+        if (MODE != MODE_TRACE) { p.agg[e] = agg; p.deagg[e] = deagg; }
+        if (MODE == MODE_RESET) {
+            p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
+            p.step_n[e] = 0;                                      // mobile_env.py:146
+            const double mean = sum_cur / (double)U;
+            if (p.out.step_n) p.out.step_n[e] = 0;
+            if (p.out.reward) p.out.reward[e] = 0.f;
+            if (p.out.reward_f64) p.out.reward_f64[e] = 0.0;
+            if (p.out.done) p.out.done[e] = 0;
+            if (p.out.n_out) p.out.n_out[e] = 0;
+            if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
+            if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
+        }
+        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+            if (depth < 3) p.fifo_depth[e] = depth + 1;
+            const double mean = sum_cur / (double)U;              // channel.py:216
+            const double r0 = mean / 20.0;                        // mobile_env.py:165
+            const double r1 = -1.0 * (double)n_outage / (double)U;  // mobile_env.py:167
+            double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
+            if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
+            step_n += 1;                                          // mobile_env.py:181
+            p.step_n[e] = step_n;
+            if (p.out.step_n) p.out.step_n[e] = step_n;
+            if (p.out.done) p.out.done[e] = (uint8_t)(step_n >= p.max_step);  // mobile_env.py:186-187
+            if (p.out.reward) p.out.reward[e] = (float)reward;
+            if (p.out.reward_f64) p.out.reward_f64[e] = reward;
+            if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
+            if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
+            if (p.out.n_out) p.out.n_out[e] = n_outage;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.state planes: GetGridMap (ue_mobility.py:173-188) + GetCurrentAssociationMap (channel.py:387-409).
+// obs is zero-filled by the caller (hipMemsetAsync); one thread per (env, node); counts add.
+__global__ __launch_bounds__(256) void obs_scatter_kernel(long long N, int U, int B, int G, const int32_t *bs_xy,
+                                                          const int16_t *ue_xy, const int8_t *serving, float *obs) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = U + B;
+    if (t >= N * per) return;
+    const long long e = t / per;
+    const int k = (int)(t - e * per);
+    const long long plane = (long long)G * G;
+    int x, y, pl;
+    if (k < B) { x = bs_xy[(e * B + k) * 2]; y = bs_xy[(e * B + k) * 2 + 1]; pl = 0; }
+    else {
+        const int u = k - B;
+        x = ue_xy[(e * U + u) * 2]; y = ue_xy[(e * U + u) * 2 + 1]; pl = 1 + serving[e * U + u];
+    }
+    if (x < 0 || x >= G || y < 0 || y >= G) return;  // the reference would raise IndexError
+    atomicAdd(&obs[(e * (B + 1) + pl) * plane + (long long)x * G + y], 1.0f);
+}
+
+}  // namespace uavk

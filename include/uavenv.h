@@ -1,0 +1,144 @@
+/*
+ * include/uavenv.h -- C ABI of libuavenv: the MI355X (gfx950) batched UAV-cellular environment.
+ *
+ * The reference (SamKnightGit/DRL_UAV_CellularNet) has no FFI layer: its boundary is the Python
+ * class MobiEnvironment (mobile_env.py:35).  This header is what a binding for that class binds
+ * (see INTEGRATION.md for the ctypes stub).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - plain C, no HIP/torch types: streams travel as void* (a hipStream_t), buffers as raw pointers;
+ *  - every *_dev pointer is CALLER-OWNED DEVICE memory on the handle's device; NULL output pointers
+ *    are skipped; the library never allocates inside reset/step (graph-capture safe);
+ *  - all calls are asynchronous on the given stream and return 0 or a negative UAVENV_E_* code,
+ *    never throw; uavenv_last_error() gives a thread-local message;
+ *  - one handle is single-threaded; distinct handles are independent;
+ *  - N = n_envs, U = n_ue, B = n_bs, Gr = n_groups, G = grid.
+ */
+#ifndef UAVENV_H
+#define UAVENV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVENV_ABI_VERSION 1
+#define UAVENV_MAX_GROUPS 16
+#define UAVENV_MAX_BS 32
+
+enum {
+    UAVENV_OK = 0,
+    UAVENV_E_INVALID = -1,   /* bad argument / config            */
+    UAVENV_E_HIP = -2,       /* a HIP runtime call failed        */
+    UAVENV_E_NODEVICE = -3,  /* no usable gfx950 device          */
+    UAVENV_E_NOMEM = -4
+};
+
+/* Constants of the reference, as data.  uavenv_default_config() fills the values every reference
+ * script runs with; citations: mobile_env.py:18-32,45,49-50,76  channel.py:7,21,36,40,46-55,81-82
+ * ue_mobility.py:436,450-451,473,487. */
+typedef struct UavEnvConfig {
+    int32_t n_bs, n_ue, n_groups, grid;
+    int32_t group_size[UAVENV_MAX_GROUPS]; /* walkers per RPGM group, sum == n_ue (mobile_env.py:76) */
+    int32_t bs_init_xy[UAVENV_MAX_BS][2];  /* UAV start cells (mobile_env.py:49-50)                  */
+    int32_t max_step;                      /* MAXSTEP = 2000                                          */
+    int32_t bs_step;                       /* BS_STEP = 2                                             */
+    int32_t min_bs_dist;                   /* MIN_BS_DIST + BS_STEP = 4 (mobile_env.py:157)           */
+    int32_t n_act;                         /* N_ACT = 5                                               */
+    int32_t agg_init, deagg_len, agg_len;  /* 200, 100, 10                                            */
+    int32_t _pad;
+    double grid_width;                     /* metres per cell = 5                                     */
+    double p_bs_dbm, noise_dbm;            /* 20, -121                                                */
+    double pl_a, pl_b, pl_dis;             /* 38, 30, 0                                               */
+    double antenna_gain, eq_loss;          /* 2, 0                                                    */
+    double shadow_mean, shadow_sd;         /* 0, 2                                                    */
+    double ho_thresh_db, out_thresh;       /* 1, 0                                                    */
+    double ue_velocity, grp_v_min, grp_v_max, aggregation; /* 1, 0, 1, 0.8                           */
+} UavEnvConfig;
+
+/* Injected randomness (parity mode).  A NULL struct pointer, or NULL members, select the on-device
+ * Philox4x32-10 streams (key = seed, counter = (env id, tick, index, draw site)). */
+typedef struct UavEnvInitInject {
+    const double *u_x_dev, *u_y_dev, *u_th_dev; /* [N,U]    uniforms, ue_mobility.py:434-437        */
+    const double *u_g_dev;                      /* [N,5,Gr] g_x,g_y,g_fl,g_v,g_theta  :442-446      */
+} UavEnvInitInject;
+
+typedef struct UavEnvInject {
+    const double *theta_u_dev; /* [N,U]    heading uniforms drawn this tick      ue_mobility.py:508    */
+    const double *group_u_dev; /* [N,Gr,3] (theta,fl,v) uniforms of arriving groups  :517-521          */
+    const double *fading_dev;  /* [N,U,B]  N(mean,sd) shadowing draws, UE-major   channel.py:240,254-256 */
+} UavEnvInject;
+
+/* Per-step outputs = what MobiEnvironment.step returns / exposes (mobile_env.py:150-194,231-232). */
+typedef struct UavEnvOut {
+    float *reward_dev;      /* [N]     max(meanSINR/20 - nOut/U, -1)   mobile_env.py:163-189        */
+    uint8_t *done_dev;      /* [N]     step_n >= MAXSTEP               mobile_env.py:186-187        */
+    float *mean_sinr_dev;   /* [N]     np.mean(current_BS_sinr)        channel.py:216               */
+    int32_t *n_out_dev;     /* [N]     newly outaged UEs               channel.py:170-174           */
+    int16_t *ue_xy_dev;     /* [N,U,2] env.ueLoc                       mobile_env.py:154-155        */
+    int32_t *bs_xy_dev;     /* [N,B,2] env.bsLoc[:, :2]                mobile_env.py:157            */
+    int8_t *serving_dev;    /* [N,U]   channel.current_BS (post handover) channel.py:162-167        */
+    float *cur_sinr_dev;    /* [N,U]   channel.current_BS_sinr         channel.py:145-146           */
+    int32_t *step_n_dev;    /* [N]     env.step_n                                                   */
+    double *cur_sinr_f64_dev, *mean_sinr_f64_dev, *reward_f64_dev; /* optional float64 copies       */
+} UavEnvOut;
+
+/* Byte offsets of every persistent per-env field inside the state blob (get/set_state). */
+typedef struct UavEnvStateLayout {
+    size_t total_bytes;
+    size_t ue_x, ue_y, ue_hu;                     /* f64 [N,U]                                        */
+    size_t g_x, g_y, g_fl, g_v, g_cos, g_sin;     /* f64 [N,Gr]                                       */
+    size_t agg, deagg;                            /* i32 [N]                                          */
+    size_t tick;                                  /* u32 [N]                                          */
+    size_t bs_xy;                                 /* i32 [N,B,2]                                      */
+    size_t serving;                               /* i8  [N,U]                                        */
+    size_t fifo;                                  /* i8  [N,3,U]   bestBS_buf, oldest row first       */
+    size_t fifo_depth;                            /* i32 [N]                                          */
+    size_t out_bits;                              /* u64 [N,ceil(U/64)]  previous outage set          */
+    size_t step_n;                                /* i32 [N]                                          */
+    size_t ue_xy;                                 /* i16 [N,U,2]                                      */
+} UavEnvStateLayout;
+
+typedef struct uavenv uavenv_t;
+
+int uavenv_abi_version(void);
+const char *uavenv_last_error(void);
+
+/* Reference constants for (n_bs, n_ue, grid); 4 equal groups; the 4-UAV layout when n_bs == 4. */
+int uavenv_default_config(UavEnvConfig *cfg, int n_bs, int n_ue, int grid);
+
+/* Allocate N envs on `device`.  env_id_base offsets the Philox env id (rank * N for sharding). */
+int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device, uint64_t seed, uint32_t env_id_base,
+                  uavenv_t **out);
+void uavenv_destroy(uavenv_t *h);
+
+/* reference_point_group state construction (ue_mobility.py:433-451) + UAVs to their start cells. */
+int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *stream);
+/* n_ticks x next(self.mm) without a channel update (mobile_env.py:77-79).  With injection n_ticks must be 1. */
+int uavenv_warmup(uavenv_t *h, int n_ticks, const UavEnvInject *inj, void *stream);
+/* MobiEnvironment.reset (mobile_env.py:115-148) for envs with mask_dev[e] != 0 (NULL: all).  Also the
+ * tail of the constructor: last warm-up tick + LTEChannel.__init__ (mobile_env.py:94-98, channel.py:92-93,110). */
+int uavenv_reset(uavenv_t *h, const uint8_t *mask_dev, const UavEnvInject *inj, const UavEnvOut *out, void *stream);
+/* MobiEnvironment.step (mobile_env.py:150-194): one fused kernel launch for all N envs. */
+int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj, const UavEnvOut *out,
+                void *stream);
+/* MobiEnvironment.step_test in read_trace mode (mobile_env.py:196-233): UE cells come from ue_xy_in_dev [N,U,2]. */
+int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
+                      const UavEnvInject *inj, const UavEnvOut *out, void *stream);
+/* env.state: (N, B+1, G, G) float32 count planes (mobile_env.py:139-140,169-170; ue_mobility.py:173-188;
+ * channel.py:387-409).  Full rewrite of obs_dev. */
+int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream);
+
+/* copy.deepcopy(env) (gradient.py:15) / checkpointing: the whole persistent state as one blob. */
+int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout);
+int uavenv_get_state(uavenv_t *h, void *dst, int dst_is_device, void *stream);
+int uavenv_set_state(uavenv_t *h, const void *src, int src_is_device, void *stream);
+
+/* Philox4x32-10 of one counter/key on the HOST (known-answer tests of the generator the kernels use). */
+void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVENV_H */

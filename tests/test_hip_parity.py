@@ -1,0 +1,240 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libuavenv.so), against
+ (1) the golden vectors captured from the real reference (injected randomness), and
+ (2) the CPU oracle on the same Philox streams (on-device randomness), and
+ (3) size-independent properties at BASELINE.json's full sizes.
+Bar: integers (UE/UAV cells, serving UAV, FIFO, outage set/count, step counter, done) bit-exact;
+float32 SINR / mean / reward within 1e-5 relative (north_star); float64 copies within 1e-9."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F32_RTOL = 1e-5
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _make(n, fx=None, **kw):
+    _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    if fx is not None:
+        kw.update(nBS=fx["n_bs"], nUE=fx["n_ue"], grid_n=fx["grid"], groups=list(fx["groups"]),
+                  bs_init=[tuple(r) for r in fx["bs_init"]], max_step=int(fx["max_step"]))
+    return BatchedMobiEnv(n, **kw)
+
+
+def test_hip_replays_reference(golden):
+    """Injected draws: every event of every fixture, 3 identical envs per fixture."""
+    from hip_adapter import HipEnvAdapter
+    from replay import make_checker, replay_fixture
+
+    fx = golden
+    N = 3
+    env = _make(N, fx, f64_outputs=True, construct=False)
+    ad = HipEnvAdapter(env)
+    U, Gr, W = fx["n_ue"], fx["n_groups"], fx["warmup_ticks"]
+    stats = {}
+    base = make_checker(fx, N, f64_tol=1e-9, f32_rtol=F32_RTOL, stats=stats)
+    long_fx = len(fx["ev_kind"]) > 400
+
+    def check(e, kind, out, ad):
+        base(e, kind, out, ad)
+        if long_fx and e % 50 and e < len(fx["ev_kind"]) - 20:
+            return  # state blob download is slow-ish; sample it on the 2000-event episode
+        s = ad.s
+        if kind == "ctor":
+            ref = fx["mob_after_warmup"]
+            for n in range(N):
+                np.testing.assert_allclose(s["ue_x"][n], ref[:U], rtol=0, atol=1e-9)
+                np.testing.assert_allclose(s["ue_y"][n], ref[U:2 * U], rtol=0, atol=1e-9)
+                o = 4 * U
+                for i, k in enumerate(("g_x", "g_y", "g_fl", "g_v", "g_cos", "g_sin")):
+                    np.testing.assert_allclose(s[k][n], ref[o + i * Gr:o + (i + 1) * Gr], rtol=0, atol=1e-9, err_msg=k)
+                assert s["agg"][n] == int(ref[o + 6 * Gr]) and s["deagg"][n] == int(ref[o + 6 * Gr + 1])
+                np.testing.assert_array_equal(_bits(s["out_bits"][n], U), fx["init_out_mask"])
+            return
+        for n in range(N):
+            if e < fx["tick_pos"].shape[0]:
+                np.testing.assert_allclose(np.stack([s["ue_x"][n], s["ue_y"][n]], 1), fx["tick_pos"][e], rtol=0,
+                                           atol=1e-9)
+            np.testing.assert_allclose(s["g_fl"][n], fx["tick_g_fl"][W + e], rtol=0, atol=1e-9)
+            depth = int(fx["fifo_depth"][e])
+            assert int(s["fifo_depth"][n]) == depth
+            np.testing.assert_array_equal(s["fifo"][n][:depth], fx["fifo"][e][:depth])
+            np.testing.assert_array_equal(_bits(s["out_bits"][n], U), fx["out_mask"][e])
+        if e % 16 == 0 or e < 4:  # dense observation == the reference's state tensor
+            obs = env.dense_obs().cpu().numpy()
+            for n in range(N):
+                nz = np.argwhere(obs[n] != 0)
+                got = sorted((int(p), int(x), int(y), int(obs[n][p, x, y])) for p, x, y in nz)
+                want = sorted(tuple(int(v) for v in r) for r in fx["state_nz"][e] if r[0] >= 0)
+                assert got == want
+
+    replay_fixture(ad, fx, N, check)
+    assert stats["events"] == len(fx["ev_kind"]) + 1
+
+
+def _bits(words, U):
+    return np.array([(int(words[u // 64]) >> (u % 64)) & 1 for u in range(U)], bool)
+
+
+@pytest.mark.parametrize("shape", [(4, 20, 100, 64, 96), (4, 40, 200, 16, 40), (16, 200, 100, 8, 24), (7, 33, 64, 8, 24)])
+def test_hip_matches_oracle_on_philox_streams(shape):
+    """No injection: device Philox/Box-Muller vs the oracle's, construct + reset + steps + masked reset."""
+    torch = _torch()
+    from oracle import oracle as O
+
+    B, U, G, N, T = shape
+    groups = None
+    if U % 4:
+        groups = [U // 4] * 3 + [U - 3 * (U // 4)]
+    bs_init = None
+    if B != 4:
+        side = int(np.ceil(np.sqrt(B)))
+        bs_init = [(G // (2 * side) + (b // side) * (G // side), G // (2 * side) + (b % side) * (G // side))
+                   for b in range(B)]
+    seed, base = 0xC0FFEE1234, 1000
+    env = _make(N, nBS=B, nUE=U, grid_n=G, groups=groups, bs_init=bs_init, seed=seed, env_id_base=base,
+                f64_outputs=True)
+    ocfg = O.make_config(B, U, G, groups=groups if groups else [U // 4] * 4, bs_init=bs_init)
+    orc = O.OracleEnv(ocfg, N, seed=seed, env_id_base=base)
+    oo = orc.construct()
+    rs = np.random.RandomState(7)
+
+    def compare(tag):
+        torch.cuda.synchronize()
+        g = {k: v.cpu().numpy() for k, v in env.out.items()}
+        for k in ("ue_xy", "bs_xy", "serving", "step_n", "n_out", "done"):
+            np.testing.assert_array_equal(g[k], oo[k], err_msg="%s %s" % (tag, k))
+        for k in ("cur_sinr", "mean_sinr", "reward"):
+            np.testing.assert_allclose(g[k], oo[k], rtol=F32_RTOL, atol=0, err_msg="%s %s" % (tag, k))
+        for k in ("cur_sinr_f64", "mean_sinr_f64", "reward_f64"):
+            np.testing.assert_allclose(g[k], oo[k], rtol=1e-9, atol=1e-9, err_msg="%s %s" % (tag, k))
+
+    compare("ctor")
+    for t in range(T):
+        a = rs.randint(0, 5, size=(N, B)).astype(np.int64)
+        act = np.zeros(N, np.int64)
+        for b in range(B):
+            act = act * 5 + a[:, b]
+        if t == T // 2:  # masked reset of every other env, as a caller would do on `done`
+            mask = (np.arange(N) % 2).astype(np.uint8)
+            env.reset(mask=mask)
+            oo = orc.reset(mask=mask)
+            torch.cuda.synchronize()
+            g = {k: v.cpu().numpy() for k, v in env.out.items()}
+            sel = mask.astype(bool)
+            for k in ("ue_xy", "bs_xy", "serving", "step_n"):
+                np.testing.assert_array_equal(g[k][sel], oo[k][sel], err_msg="masked reset " + k)
+        env.step(torch.as_tensor(act, device=env.device))
+        oo = orc.step(act)
+        compare("step %d" % t)
+    s = env.state_fields()
+    for k in ("ue_x", "ue_y", "g_x", "g_y", "g_fl", "g_v", "g_cos", "g_sin"):
+        np.testing.assert_allclose(s[k], orc.s[k], rtol=0, atol=1e-9, err_msg=k)
+    for k in ("agg", "deagg", "tick", "bs_xy", "serving", "fifo_depth", "out_bits", "step_n", "ue_xy"):
+        np.testing.assert_array_equal(s[k], orc.s[k], err_msg=k)
+    np.testing.assert_array_equal(env.dense_obs().cpu().numpy(), orc.obs_dense())
+
+
+def test_full_size_properties_4096_envs():
+    """BASELINE config 2 (4096 envs, 4 UAV x 20 UE): invariants the reference guarantees."""
+    torch = _torch()
+    N, B, U, G = 4096, 4, 20, 100
+    env = _make(N, nBS=B, nUE=U, grid_n=G)
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    bs0 = env.out["bs_xy"].clone()
+    for t in range(40):
+        a = torch.randint(0, 625, (N,), generator=gen).to(env.device)
+        obs, reward, done, info = env.step(a)
+        assert int(info["step_n"].min()) == t + 1 == int(info["step_n"].max())
+        assert float(reward.min()) >= -1.0
+        assert not bool(done.any())
+        ue = obs["ue_xy"]
+        assert int(ue.min()) >= 0 and int(ue.max()) <= G - 1
+        bs = obs["bs_xy"]
+        assert int(bs.min()) >= 2 and int(bs.max()) <= G - 2                # ue_mobility.py:221-235
+        assert bool(((bs - bs0) % 2 == 0).all())                            # BS_STEP = 2 keeps parity
+        assert int(obs["serving"].min()) >= 0 and int(obs["serving"].max()) < B
+        assert int(info["n_out"].min()) >= 0 and int(info["n_out"].max()) <= U
+        assert bool(torch.isfinite(info["cur_sinr"]).all())
+    dense = env.dense_obs()
+    assert torch.equal(dense[:, 0].sum(dim=(1, 2)), torch.full((N,), float(B), device=env.device))
+    assert torch.equal(dense[:, 1:].sum(dim=(1, 2, 3)), torch.full((N,), float(U), device=env.device))
+    # action 624 = "4444" is a no-op for every UAV (ue_mobility.py:237)
+    before = env.out["bs_xy"].clone()
+    env.step(torch.full((N,), 624, dtype=torch.int64, device=env.device))
+    assert torch.equal(before, env.out["bs_xy"])
+    # mean_sinr really is the mean of cur_sinr; reward formula (mobile_env.py:163-189)
+    m = env.out["cur_sinr"].double().mean(dim=1)
+    assert torch.allclose(m, env.out["mean_sinr"].double(), rtol=1e-5, atol=1e-5)
+    r = torch.clamp(env.out["mean_sinr"].double() / 20 - env.out["n_out"].double() / U, min=-1.0)
+    assert torch.allclose(r, env.out["reward"].double(), rtol=1e-5, atol=1e-6)
+
+
+def test_sharding_and_determinism():
+    """Env e of a big batch == env 0 of a batch created with env_id_base = e (what a rank's shard is);
+    and two handles with the same seed produce identical trajectories."""
+    torch = _torch()
+    N = 512
+    big = _make(N, nBS=4, nUE=20, grid_n=100, seed=99)
+    again = _make(N, nBS=4, nUE=20, grid_n=100, seed=99)
+    shard = _make(128, nBS=4, nUE=20, grid_n=100, seed=99, env_id_base=256)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for t in range(12):
+        a = torch.randint(0, 625, (N,), generator=gen).to(big.device)
+        big.step(a)
+        again.step(a)
+        shard.step(a[256:384].contiguous())
+        for k in ("ue_xy", "bs_xy", "serving", "cur_sinr", "reward", "n_out"):
+            assert torch.equal(big.out[k], again.out[k]), k
+            assert torch.equal(big.out[k][256:384], shard.out[k]), k
+    other = _make(N, nBS=4, nUE=20, grid_n=100, seed=100)
+    assert not torch.equal(other.out["ue_xy"], big.out["ue_xy"])
+
+
+def test_done_and_state_roundtrip_and_clone():
+    torch = _torch()
+    N = 64
+    env = _make(N, nBS=4, nUE=20, grid_n=100, max_step=5)
+    a = torch.full((N,), 624, dtype=torch.int64, device=env.device)
+    for t in range(5):
+        _, _, done, info = env.step(a)
+        assert bool(done.all()) == (t == 4)                                 # mobile_env.py:186-187
+    env.reset()
+    assert int(env.out["step_n"].max()) == 0
+    blob = env.get_state()
+    twin = env.clone()                                                      # gradient.py:15 deepcopy(env)
+    outs = []
+    for t in range(3):
+        env.step(a)
+        outs.append({k: v.clone() for k, v in env.out.items()})
+    for t in range(3):
+        twin.step(a)
+        for k, v in twin.out.items():
+            assert torch.equal(v, outs[t][k]), k
+    env.set_state(blob)
+    for t in range(3):
+        env.step(a)
+        for k, v in env.out.items():
+            assert torch.equal(v, outs[t][k]), k
+
+
+def test_bad_arguments_fail_loudly():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, UavEnvError
+
+    with pytest.raises(UavEnvError):
+        BatchedMobiEnv(8, nBS=40)
+    with pytest.raises(ValueError):
+        BatchedMobiEnv(8, nBS=4, nUE=20, groups=[5, 5, 5])
+    env = BatchedMobiEnv(8)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(7, dtype=torch.int64, device=env.device))
