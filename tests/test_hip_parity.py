@@ -160,7 +160,9 @@ def test_full_size_properties_4096_envs():
         ue = obs["ue_xy"]
         assert int(ue.min()) >= 0 and int(ue.max()) <= G - 1
         bs = obs["bs_xy"]
-        assert int(bs.min()) >= 2 and int(bs.max()) <= G - 2                # ue_mobility.py:221-235
+        # ue_mobility.py:221-235: +2 only while x+2 < G, -2 only while x-2 > 1  =>  2 <= x <= G-1
+        # (SURVEY.md section 4 says [2, G-2]; the reference's own guards allow G-1, e.g. 97+2=99 < 100)
+        assert int(bs.min()) >= 2 and int(bs.max()) <= G - 1
         assert bool(((bs - bs0) % 2 == 0).all())                            # BS_STEP = 2 keeps parity
         assert int(obs["serving"].min()) >= 0 and int(obs["serving"].max()) < B
         assert int(info["n_out"].min()) >= 0 and int(info["n_out"].max()) <= U
