@@ -22,6 +22,7 @@ struct uavenv {
     uint64_t seed;
     uint32_t env_id_base;
     int bt;  // template bound on B
+    bool plc;  // pl_b == 30: cube path-loss kernel variant
     char *blob;
     int32_t *bs_init_dev;
     UavEnvStateLayout lay;
@@ -158,6 +159,13 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.grid_width = cfg->grid_width;
     k.p_bs_watt = std::pow(10.0, cfg->p_bs_dbm / 10.0) * 1e-3;    // channel.py:58
     k.noise_watt = std::pow(10.0, cfg->noise_dbm / 10.0) * 1e-3;  // channel.py:59
+    // folded constants of the linear-domain gain (see env_kernel): float64 pow on the host, once
+    k.k_pl = k.p_bs_watt * std::pow(10.0, (cfg->antenna_gain - cfg->pl_a - cfg->eq_loss) / 10.0);
+    k.k_0 = k.p_bs_watt * std::pow(10.0, (cfg->antenna_gain - cfg->eq_loss) / 10.0);
+    k.c_exp = -std::log2(10.0) / 10.0;      // 10^(-f/10) = 2^(c_exp*f)
+    k.pl_exp = cfg->pl_b / 10.0;            // d^(-pl_b/10) = 2^(-pl_exp*log2(d))
+    k.db_per_log2 = 10.0 / std::log2(10.0); // 10*log10(x) = db_per_log2*log2(x)
+    h->plc = (cfg->pl_b == 30.0);
     k.pl_a = cfg->pl_a; k.pl_b = cfg->pl_b; k.pl_dis = cfg->pl_dis; k.antenna_gain = cfg->antenna_gain;
     k.eq_loss = cfg->eq_loss; k.shadow_mean = cfg->shadow_mean; k.shadow_sd = cfg->shadow_sd;
     k.ho_thresh_db = cfg->ho_thresh_db; k.out_thresh = cfg->out_thresh; k.ue_velocity = cfg->ue_velocity;
@@ -215,12 +223,18 @@ template <int MODE>
 static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     const unsigned grid = (unsigned)((p.N + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
+#define UAVENV_LAUNCH(BT_)                                                                        \
+    do {                                                                                          \
+        if (h->plc) hipLaunchKernelGGL((env_kernel<BT_, MODE, true>), dim3(grid), blk, 0, s, p);  \
+        else hipLaunchKernelGGL((env_kernel<BT_, MODE, false>), dim3(grid), blk, 0, s, p);        \
+    } while (0)
     switch (h->bt) {
-        case 4: hipLaunchKernelGGL((env_kernel<4, MODE>), dim3(grid), blk, 0, s, p); break;
-        case 8: hipLaunchKernelGGL((env_kernel<8, MODE>), dim3(grid), blk, 0, s, p); break;
-        case 16: hipLaunchKernelGGL((env_kernel<16, MODE>), dim3(grid), blk, 0, s, p); break;
-        default: hipLaunchKernelGGL((env_kernel<32, MODE>), dim3(grid), blk, 0, s, p); break;
+        case 4: UAVENV_LAUNCH(4); break;
+        case 8: UAVENV_LAUNCH(8); break;
+        case 16: UAVENV_LAUNCH(16); break;
+        default: UAVENV_LAUNCH(32); break;
     }
+#undef UAVENV_LAUNCH
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

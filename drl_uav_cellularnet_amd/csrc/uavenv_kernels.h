@@ -40,6 +40,7 @@ struct KParams {
     int group_start[kMaxGroups + 1];
     int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
     double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
+    double k_pl, k_0, c_exp, pl_exp, db_per_log2;  // folded constants, see the gain block in env_kernel
     double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
     long long N;
     uint32_t key0, key1, env_id_base;
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // The fused env kernel.  BT: compile-time bound on B (4/8/16/32).  MODE: see enum Mode.
-template <int BT, int MODE>
+// PLC: path-loss exponent pl_b == 30 (the reference's constant, channel.py:47) => d^-3 by sqrt, no log.
+template <int BT, int MODE, bool PLC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams p) {
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
     const int lane = threadIdx.x & 63;
@@ -236,9 +238,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
                 x = x + p.ue_velocity * cs;               // :455
                 y = y + p.ue_velocity * sn;               // :456
                 if (aggregating) {                        // :461-470
-                    const double c = atan2(gy - y, gx - x);
-                    double sc, cc;
-                    sincos(c, &sc, &cc);
+                    // cos/sin of c_theta = arctan2(g_y - y, g_x - x) (:467) are the normalised components of
+                    // the vector to the group centre; arctan2(0, 0) = 0 gives (1, 0).
+                    const double dxc = gx - x, dyc = gy - y;
+                    const double r2 = dxc * dxc + dyc * dyc;
+                    const double rinv = 1.0 / sqrt(r2);
+                    const double cc = (r2 > 0.0) ? dxc * rinv : 1.0;
+                    const double sc = (r2 > 0.0) ? dyc * rinv : 0.0;
                     x = x + gv * gc + p.aggregation * cc;
                     y = y + gv * gs + p.aggregation * sc;
                 } else {                                  // :476-484
@@ -281,8 +287,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
             if (MODE == MODE_WARMUP) continue;
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
-            // ---- gains + DL SINR for walker u against every UAV (channel.py:220-269) ------------
-            double pg[BT], sinr[BT];
+            // ---- received power of every UAV at walker u (channel.py:220-257), linear domain ---------
+            // The reference goes through dB and back (loss = a + b*log10(d); gain = 10^((ant-loss-f-eq)/10)).
+            // Same value with fewer transcendentals:
+            //     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3, no log at all)
+            //            = k_0  * 10^(-f/10)               otherwise (loss = 0)
+            // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
+            double pg[BT];
 #pragma unroll
             for (int b2 = 0; b2 < BT; b2 += 2) {
                 double f0 = 0.0, f1 = 0.0;
@@ -308,31 +319,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
                     if (b < BT) {
                         double g = 0.0;
                         if (b < B) {
+                            const double f = (k == 0) ? f0 : f1;
                             const double fx = p.grid_width * (double)(ix - s_bs[wave][2 * b]);       // :221-222
                             const double fy = p.grid_width * (double)(iy - s_bs[wave][2 * b + 1]);
                             const double d = sqrt(fx * fx + fy * fy);                                 // :223 (z ignored)
-                            double loss = 0.0;                                                        // :232
-                            if (d > p.pl_dis) loss = p.pl_a + p.pl_b * log10(d);                      // :233-234
-                            const double gdb = p.antenna_gain - loss - (k == 0 ? f0 : f1) - p.eq_loss;  // :245
-                            g = exp10(gdb * 0.1);                                                     // :246
+                            if (PLC) g = p.k_pl * exp2(p.c_exp * f) / (d * d * d);
+                            else g = p.k_pl * exp2(p.c_exp * f - p.pl_exp * log2(d));
+                            if (!(d > p.pl_dis)) g = p.k_0 * exp2(p.c_exp * f);                       // :232-233
                         }
-                        pg[b] = p.p_bs_watt * g;
+                        pg[b] = g;
                     }
                 }
             }
+            // best UAV: SINR_b = pg_b / (noise + sum_{j != b} pg_j) is strictly increasing in pg_b (the total
+            // is fixed), so np.argmax over the dB values (:141) == first maximum of pg.
             int best = 0;
-            double bestS = -1.0e300;
+            double bp = pg[0];
 #pragma unroll
-            for (int b = 0; b < BT; ++b) {
-                double interf = 0.0;  // sum over the OTHER UAVs in index order (:263-265); never total - self
+            for (int b = 1; b < BT; ++b)
+                if (b < B && pg[b] > bp) { bp = pg[b]; best = b; }
+            // 10*log10(S/(N+I)) for one UAV x (:259-268); interference = the OTHER UAVs summed in index order,
+            // never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
+            auto sinr_db = [&](int x) {
+                double interf = 0.0, px = 0.0;
 #pragma unroll
-                for (int j = 0; j < BT; ++j)
-                    if (j != b && j < B) interf += pg[j];
-                double s = -1.0e300;
-                if (b < B) s = 10.0 * log10(pg[b] / (p.noise_watt + interf));  // :266-268
-                sinr[b] = s;
-                if (s > bestS) { bestS = s; best = b; }  // np.argmax: first maximum (:141-142)
-            }
+                for (int j = 0; j < BT; ++j) {
+                    interf += (j != x && j < B) ? pg[j] : 0.0;
+                    px = (j == x) ? pg[j] : px;
+                }
+                return p.db_per_log2 * log2(px / (p.noise_watt + interf));
+            };
+            const double bestS = sinr_db(best);
 
             if (MODE == MODE_RESET) {
                 // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
@@ -354,9 +371,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
                     serving = p.serving[iu];
                     r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
                 }
-                double cur = 0.0;  // SINR of the serving UAV BEFORE any handover (:145-146)
-#pragma unroll
-                for (int b = 0; b < BT; ++b) cur = (b == serving) ? sinr[b] : cur;
+                const double cur = sinr_db(serving);  // SINR of the serving UAV BEFORE any handover (:145-146)
                 bool remain;
                 if (depth == 1) { r1 = best; remain = (r1 == r0); }                       // append (:148-149)
                 else if (depth == 2) { r2 = best; remain = (r1 == r0) && (r2 == r0); }
