@@ -145,7 +145,7 @@ def main():
                        "envs_per_gpu": E, "n_bs": N_BS, "n_ue": N_UE, "grid": GRID, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "env_kernel<4,MODE_STEP>", "algorithmic_bytes_per_launch": b_step * E,
+                         "kernel": "env_kernel_packed<4,MODE_STEP,true>", "algorithmic_bytes_per_launch": b_step * E,
                          "avg_launch_us": per_launch_s * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:

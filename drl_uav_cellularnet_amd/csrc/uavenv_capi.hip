@@ -23,8 +23,10 @@ struct uavenv {
     uint32_t env_id_base;
     int bt;  // template bound on B
     bool plc;  // pl_b == 30: cube path-loss kernel variant
+    bool packed;  // U <= 64 and U >= max(B, Gr): env_kernel_packed with kp.epw envs per wavefront
     char *blob;
     int32_t *bs_init_dev;
+    long long *act_pow_dev;
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
 };
@@ -106,6 +108,14 @@ static int check_config(const UavEnvConfig &c) {
     }
     if (s != c.n_ue) return fail(UAVENV_E_INVALID, "config: group sizes do not sum to n_ue");
     if (c.n_act < 2 || c.n_act > 9) return fail(UAVENV_E_INVALID, "config: n_act out of range [2,9]");
+    {   // the joint action is one int64 (the reference uses unbounded Python ints): n_act^n_bs must fit
+        long long pw = 1;
+        for (int b = 0; b < c.n_bs; ++b) {
+            if (pw > 0x7FFFFFFFFFFFFFFFll / c.n_act)
+                return fail(UAVENV_E_INVALID, "config: n_act^n_bs does not fit in int64 (joint action encoding)");
+            pw *= c.n_act;
+        }
+    }
     if (c.max_step < 1 || c.bs_step < 0 || c.min_bs_dist < 0) return fail(UAVENV_E_INVALID, "config: bad step constants");
     for (int b = 0; b < c.n_bs; ++b)
         if (c.bs_init_xy[b][0] < 0 || c.bs_init_xy[b][0] >= c.grid || c.bs_init_xy[b][1] < 0 || c.bs_init_xy[b][1] >= c.grid)
@@ -143,8 +153,21 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     if (e != hipSuccess) { delete h; return fail(UAVENV_E_NOMEM, std::string("create: hipMalloc state: ") + hipGetErrorString(e)); }
     e = hipMalloc((void **)&h->bs_init_dev, sizeof(int32_t) * 2 * UAVENV_MAX_BS);
     if (e != hipSuccess) { (void)hipFree(h->blob); delete h; return fail(UAVENV_E_NOMEM, "create: hipMalloc bs_init"); }
+    e = hipMalloc((void **)&h->act_pow_dev, sizeof(long long) * UAVENV_MAX_BS);
+    if (e != hipSuccess) {
+        (void)hipFree(h->blob); (void)hipFree(h->bs_init_dev); delete h;
+        return fail(UAVENV_E_NOMEM, "create: hipMalloc act_pow");
+    }
     (void)hipMemset(h->blob, 0, L.total_bytes);
     (void)hipMemcpy(h->bs_init_dev, cfg->bs_init_xy, sizeof(int32_t) * 2 * UAVENV_MAX_BS, hipMemcpyHostToDevice);
+    // act_pow[b] = n_act^(B-1-b): digit of UAV b in the joint action, most significant first
+    // (Decimal_to_Base_N, ue_mobility.py:310-336).  check_config() has verified n_act^B fits in int64.
+    long long act_pow[UAVENV_MAX_BS];
+    std::memset(act_pow, 0, sizeof(act_pow));
+    long long pw = 1;
+    for (int b = cfg->n_bs - 1; b >= 0; --b) { act_pow[b] = pw; pw *= cfg->n_act; }
+    const long long n_joint = pw;  // n_act^B = action_space_dim (mobile_env.py:104)
+    (void)hipMemcpy(h->act_pow_dev, act_pow, sizeof(act_pow), hipMemcpyHostToDevice);
 
     KParams &k = h->kp;
     std::memset(&k, 0, sizeof(k));
@@ -180,6 +203,15 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.fifo_depth = (int32_t *)(b + L.fifo_depth); k.out_bits = (unsigned long long *)(b + L.out_bits);
     k.step_n = (int32_t *)(b + L.step_n); k.ue_xy = (int16_t *)(b + L.ue_xy);
     k.bs_init = h->bs_init_dev;
+    k.act_pow = h->act_pow_dev;
+    k.act32 = (n_joint <= 0xFFFFFFFFll) ? 1 : 0;  // 32-bit digit extraction when every joint action fits
+    // Packed kernel: floor(64/U) env instances per wavefront; needs the group / UAV owner lanes inside a slot.
+    h->packed = (cfg->n_ue <= 64) && (cfg->n_ue >= cfg->n_bs) && (cfg->n_ue >= cfg->n_groups);
+    k.epw = 1;
+    if (h->packed) {
+        k.epw = 64 / cfg->n_ue;
+        if (k.epw > kMaxEpw) k.epw = kMaxEpw;
+    }
     *out = h;
     return UAVENV_OK;
 }
@@ -189,6 +221,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->blob);
     (void)hipFree(h->bs_init_dev);
+    (void)hipFree(h->act_pow_dev);
     delete h;
 }
 
@@ -221,12 +254,19 @@ extern "C" int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *strea
 
 template <int MODE>
 static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
-    const unsigned grid = (unsigned)((p.N + kWavesPerBlock - 1) / kWavesPerBlock);
+    // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
+    const long long waves = (p.N + p.epw - 1) / p.epw;
+    const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
-#define UAVENV_LAUNCH(BT_)                                                                        \
-    do {                                                                                          \
-        if (h->plc) hipLaunchKernelGGL((env_kernel<BT_, MODE, true>), dim3(grid), blk, 0, s, p);  \
-        else hipLaunchKernelGGL((env_kernel<BT_, MODE, false>), dim3(grid), blk, 0, s, p);        \
+#define UAVENV_LAUNCH(BT_)                                                                                     \
+    do {                                                                                                       \
+        if (h->packed) {                                                                                       \
+            if (h->plc) hipLaunchKernelGGL((env_kernel_packed<BT_, MODE, true>), dim3(grid), blk, 0, s, p);    \
+            else hipLaunchKernelGGL((env_kernel_packed<BT_, MODE, false>), dim3(grid), blk, 0, s, p);          \
+        } else {                                                                                               \
+            if (h->plc) hipLaunchKernelGGL((env_kernel_multipass<BT_, MODE, true>), dim3(grid), blk, 0, s, p); \
+            else hipLaunchKernelGGL((env_kernel_multipass<BT_, MODE, false>), dim3(grid), blk, 0, s, p);       \
+        }                                                                                                      \
     } while (0)
     switch (h->bt) {
         case 4: UAVENV_LAUNCH(4); break;

@@ -1,14 +1,18 @@
 // HIP kernels of the batched UAV-cellular environment for gfx950 (MI355X / CDNA4).
 //
-// Mapping: ONE WAVEFRONT (64 lanes) PER ENV INSTANCE; 4 envs per 256-thread workgroup.
-//   lane  -> UE (u = lane + 64*pass; 20/40 UEs: one pass, 200 UEs: four passes)
-//   lanes 0..Gr-1 also own one RPGM group each, lanes 0..B-1 one UAV each
-//   UAV cells are staged in LDS (one row per wave) and read back as broadcasts in the per-UE
-//   path-loss loop; gains / SINRs of the BT base stations live in registers (BT = template bound
-//   on B so every index is static); mean SINR, outage set and outage count are wavefront
-//   reductions (shuffles / ballots).  No MFMA: there is no dense contraction on this path.
-//   All arithmetic is float64 (float32 breaks the 1e-5 relative bound near 0 dB
-//   and can flip handover / outage decisions); outputs are rounded to float32 once.
+// Mapping.  The unit of work is one env instance; its walkers (UEs) are lanes of ONE wavefront, so every
+// per-env reduction (mean SINR, outage set/count, bounce flags, UAV collision test) is a wavefront ballot or
+// shuffle reduction and never touches LDS atomics or another wave.
+//   env_kernel_packed  (U <= 64): a wavefront hosts EPW = floor(64/U) env instances side by side
+//                      ("slots": lanes [s*U, (s+1)*U)), e.g. 3 envs at 20 UEs, 1 env at 40 UEs.  Ballots are
+//                      masked with the slot's lane mask, sums are segmented shuffle reductions.
+//   env_kernel_multipass (U > 64): one env per wavefront, walkers in passes of 64 (200 UEs: 4 passes).
+//   In a slot, lanes 0..Gr-1 also own one RPGM group each and lanes 0..B-1 one UAV each.
+//   UAV cells are staged in LDS (one row per slot) and read back in the per-UE path-loss loop; received
+//   powers of the BT UAVs live in registers (BT = template bound on B, so every index is static).
+//   No MFMA: there is no dense contraction on this path.  Arithmetic is float64 throughout (SURVEY.md H2:
+//   float32 breaks the 1e-5 relative bound near 0 dB and flips handover/outage decisions); outputs are
+//   rounded to float32 once.
 //
 // What the code follows in the reference (/root/reference):
 //   mobility tick      ue_mobility.py:453-523     UAV move   ue_mobility.py:191-271,310-336
@@ -25,6 +29,7 @@ namespace uavk {
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxGroups = 16;
 constexpr int kMaxBs = 32;
+constexpr int kMaxEpw = 8;  // env instances per wavefront (packed kernel)
 
 enum Mode : int { MODE_WARMUP = 0, MODE_RESET = 1, MODE_STEP = 2, MODE_TRACE = 3 };
 
@@ -36,11 +41,11 @@ struct OutPtrs {
 
 struct KParams {
     // shape / constants
-    int U, B, Gr, G, W64;
+    int U, B, Gr, G, W64, epw, act32;
     int group_start[kMaxGroups + 1];
     int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
     double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
-    double k_pl, k_0, c_exp, pl_exp, db_per_log2;  // folded constants, see the gain block in env_kernel
+    double k_pl, k_0, c_exp, pl_exp, db_per_log2;  // folded constants, see rx_power()
     double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
     long long N;
     uint32_t key0, key1, env_id_base;
@@ -48,7 +53,8 @@ struct KParams {
     double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
     int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
     unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
-    const int32_t *bs_init;  // [B,2] device copy of the start cells
+    const int32_t *bs_init;      // [B,2] device copy of the start cells
+    const long long *act_pow;    // [B]   n_act^(B-1-b): joint action -> digit of UAV b (most significant first)
     // per-call inputs
     const double *inj_theta, *inj_group, *inj_fading;
     const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
@@ -65,9 +71,23 @@ struct InitParams {
     const double *u_x, *u_y, *u_th, *u_g;
 };
 
+// ================================================================================================
+// shared device helpers (both env kernels run exactly this arithmetic)
+// ================================================================================================
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over the U (<= 64) consecutive lanes of a slot; the result is valid in the slot's first lane (ul == 0).
+__device__ __forceinline__ double slot_sum(double v, int ul, int U) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_down(v, off, 64);
+        if (ul + off < U) v += t;
+    }
     return v;
 }
 
@@ -78,8 +98,212 @@ __device__ __forceinline__ void philox_u2(const KParams &p, uint32_t env, uint32
     u1 = u53(r.z, r.w);
 }
 
-// ------------------------------------------------------------------------------------------------
-// state construction: ue_mobility.py:433-451 + mobile_env.py:58-59.  One thread per (env, walker).
+// Digit of UAV b in the joint action: Decimal_to_Base_N (ue_mobility.py:310-336), most significant digit ->
+// UAV 0.  One division per UAV lane, all UAVs in parallel (pw = n_act^(B-1-b)).
+__device__ __forceinline__ int action_digit(const KParams &p, long long a, long long pw) {
+    if (p.act32) return (int)(((uint32_t)a / (uint32_t)pw) % (uint32_t)p.n_act);
+    return (int)(((unsigned long long)a / (unsigned long long)pw) % (unsigned long long)p.n_act);
+}
+
+// Proposed cell of one UAV for digit di (ue_mobility.py:221-253; bounds mobile_env.py:45).
+__device__ __forceinline__ void uav_propose(const KParams &p, int xi, int yi, int di, int &nx, int &ny) {
+    const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;
+    const int s = p.bs_step, sl = 2 * p.bs_step;
+    nx = xi; ny = yi;
+    if (di == 0) { if (xi + s < xMax) nx = xi + s; }
+    else if (di == 1) { if (xi - s > xMin) nx = xi - s; }
+    else if (di == 2) { if (yi + s < yMax) ny = yi + s; }
+    else if (di == 3) { if (yi - s > yMin) ny = yi - s; }
+    else if (di == 5) { if (xi + sl < xMax) nx = xi + sl; }
+    else if (di == 6) { if (xi - sl > xMin) nx = xi - sl; }
+    else if (di == 7) { if (yi + sl < yMax) ny = yi + sl; }
+    else if (di == 8) { if (yi - sl > yMin) ny = yi - sl; }
+}
+
+// One next() of reference_point_group for one walker (ue_mobility.py:455-505): own step along the heading
+// drawn last tick, group step (+ pull towards the group centre while aggregating), then the four ordered
+// bounce tests.  c[k] report which tests fired (they flip the GROUP heading, once per group and test).
+__device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, double hu, double gx, double gy,
+                                            double gv, double gc, double gs, double MAXC, double &x, double &y,
+                                            bool c[4]) {
+    double sn, cs;
+    sincospi(2.0 * hu, &sn, &cs);             // theta = 2*pi*u  (:437,508)
+    x = x + p.ue_velocity * cs;               // :455
+    y = y + p.ue_velocity * sn;               // :456
+    // cos/sin of c_theta = arctan2(g_y - y, g_x - x) (:467) are the normalised components of the vector to the
+    // group centre; arctan2(0, 0) = 0 gives (1, 0).
+    const double dxc = gx - x, dyc = gy - y;
+    const double r2 = dxc * dxc + dyc * dyc;
+    const double rinv = 1.0 / sqrt(r2);
+    const double cc = (r2 > 0.0) ? dxc * rinv : 1.0;
+    const double sc = (r2 > 0.0) ? dyc * rinv : 0.0;
+    x = x + gv * gc;                          // :469 / :483
+    y = y + gv * gs;                          // :470 / :484
+    if (aggregating) {                        // :461-470 (per-lane select: slots may be in different phases)
+        x = x + p.aggregation * cc;
+        y = y + p.aggregation * sc;
+    }
+    c[0] = x < 0.0;                           // :490-493
+    if (c[0]) x = -x;
+    c[1] = x > MAXC;                          // :494-497
+    if (c[1]) x = 2.0 * MAXC - x;
+    c[2] = y < 0.0;                           // :498-501
+    if (c[2]) y = -y;
+    c[3] = y > MAXC;                          // :502-505
+    if (c[3]) y = 2.0 * MAXC - y;
+}
+
+// Group owner, end of tick (ue_mobility.py:493-521): bounce flips, remaining flight length, arrival redraw.
+__device__ __forceinline__ void group_finish(const KParams &p, long long e, int g, uint32_t tick, const uint32_t touched[4],
+                                             double MAXC, double &ogfl, double &ogv, double &ogc, double &ogs) {
+    const uint32_t bit = 1u << g;
+    if (touched[0] & bit) ogc = -ogc;
+    if (touched[1] & bit) ogc = -ogc;
+    if (touched[2] & bit) ogs = -ogs;
+    if (touched[3] & bit) ogs = -ogs;
+    ogfl = ogfl - ogv;                                    // :513
+    if (ogv > 0.0 && ogfl <= 0.0) {                       // :514
+        double ut, uf, uv, t1;
+        if (p.inj_group) {
+            ut = p.inj_group[(e * p.Gr + g) * 3 + 0]; uf = p.inj_group[(e * p.Gr + g) * 3 + 1];
+            uv = p.inj_group[(e * p.Gr + g) * 3 + 2];
+        } else {
+            philox_u2(p, (uint32_t)e, tick, (uint32_t)g, DOM_GROUP_A, ut, uf);
+            philox_u2(p, (uint32_t)e, tick, (uint32_t)g, DOM_GROUP_B, uv, t1);
+        }
+        sincospi(2.0 * ut, &ogs, &ogc);                   // :517-519
+        ogfl = uf * MAXC;                                 // :520 FL_MAX = max(dimensions)
+        ogv = uv * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :521
+    }
+}
+
+// Received power P*gain of every UAV at one walker (channel.py:220-257), linear domain.
+// The reference goes through dB and back (loss = a + b*log10(d); gain = 10^((ant-loss-f-eq)/10)).
+// Same value with fewer transcendentals:
+//     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3, no log at all: PLC)
+//            = k_0  * 10^(-f/10)               otherwise (loss = 0)
+// k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
+// bs: this env's UAV cells in LDS ([2*B] ints).  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
+// Philox uniforms (one call -> two UAVs), replacing np.random.normal (channel.py:240).
+template <int BT, bool PLC>
+__device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t tick, int u, bool act, long long iu,
+                                         int ix, int iy, const int *bs, double pg[BT]) {
+    const int B = p.B;
+#pragma unroll
+    for (int b2 = 0; b2 < BT; b2 += 2) {
+        double f0 = 0.0, f1 = 0.0;
+        if (b2 < B) {
+            if (p.inj_fading) {
+                if (act) {
+                    f0 = p.inj_fading[iu * B + b2];
+                    if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
+                }
+            } else {
+                double u0, u1;
+                philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
+                const double r = sqrt(-2.0 * log(1.0 - u0));
+                double sa, ca;
+                sincospi(2.0 * u1, &sa, &ca);
+                f0 = p.shadow_mean + p.shadow_sd * (r * ca);
+                f1 = p.shadow_mean + p.shadow_sd * (r * sa);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b2 + k;
+            if (b < BT) {
+                double g = 0.0;
+                if (b < B) {
+                    const double f = (k == 0) ? f0 : f1;
+                    const double fx = p.grid_width * (double)(ix - bs[2 * b]);       // :221-222
+                    const double fy = p.grid_width * (double)(iy - bs[2 * b + 1]);
+                    const double d = sqrt(fx * fx + fy * fy);                         // :223 (z ignored)
+                    if (PLC) g = p.k_pl * exp2(p.c_exp * f) / (d * d * d);
+                    else g = p.k_pl * exp2(p.c_exp * f - p.pl_exp * log2(d));
+                    if (!(d > p.pl_dis)) g = p.k_0 * exp2(p.c_exp * f);               // :232-233
+                }
+                pg[b] = g;
+            }
+        }
+    }
+}
+
+// Best UAV: SINR_b = pg_b / (noise + sum_{j != b} pg_j) is strictly increasing in pg_b (the total is fixed),
+// so np.argmax over the dB values (channel.py:141) == first maximum of pg.
+template <int BT>
+__device__ __forceinline__ int argmax_pg(const KParams &p, const double pg[BT]) {
+    int best = 0;
+    double bp = pg[0];
+#pragma unroll
+    for (int b = 1; b < BT; ++b)
+        if (b < p.B && pg[b] > bp) { bp = pg[b]; best = b; }
+    return best;
+}
+
+// 10*log10(S/(N+I)) for UAV x (channel.py:259-268); interference = the OTHER UAVs summed in index order,
+// never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
+template <int BT>
+__device__ __forceinline__ double sinr_db(const KParams &p, const double pg[BT], int x) {
+    double interf = 0.0, px = 0.0;
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+        interf += (j != x && j < p.B) ? pg[j] : 0.0;
+        px = (j == x) ? pg[j] : px;
+    }
+    return p.db_per_log2 * log2(px / (p.noise_watt + interf));
+}
+
+// bestBS_buf push + handover decision for one UE (channel.py:148-167).  r0..r2 = FIFO rows, oldest first.
+__device__ __forceinline__ void fifo_handover(const KParams &p, int depth, int best, double bestS, double cur,
+                                              int &serving, int &r0, int &r1, int &r2) {
+    bool remain;
+    if (depth == 1) { r1 = best; remain = (r1 == r0); }                       // append (:148-149)
+    else if (depth == 2) { r2 = best; remain = (r1 == r0) && (r2 == r0); }
+    else { r0 = r1; r1 = r2; r2 = best; remain = (r1 == r0) && (r2 == r0); }  // FIFO shift (:150-153)
+    const bool changed = serving != best;                                     // :156 (newest row == best)
+    if (remain && changed && (bestS - cur > p.ho_thresh_db)) serving = best;  // :155-167
+}
+
+// Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
+template <int MODE>
+__device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32_t tick, int agg, int deagg, int depth,
+                                           int step_n, double sum_cur, int n_outage) {
+    p.tick[e] = tick;
+    if (MODE != MODE_TRACE) { p.agg[e] = agg; p.deagg[e] = deagg; }
+    if (MODE == MODE_RESET) {
+        p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
+        p.step_n[e] = 0;                                      // mobile_env.py:146
+        const double mean = sum_cur / (double)p.U;
+        if (p.out.step_n) p.out.step_n[e] = 0;
+        if (p.out.reward) p.out.reward[e] = 0.f;
+        if (p.out.reward_f64) p.out.reward_f64[e] = 0.0;
+        if (p.out.done) p.out.done[e] = 0;
+        if (p.out.n_out) p.out.n_out[e] = 0;
+        if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
+        if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
+    }
+    if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+        if (depth < 3) p.fifo_depth[e] = depth + 1;
+        const double mean = sum_cur / (double)p.U;            // channel.py:216
+        const double r0 = mean / 20.0;                        // mobile_env.py:165
+        const double r1 = -1.0 * (double)n_outage / (double)p.U;  // mobile_env.py:167
+        double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
+        if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
+        step_n += 1;                                          // mobile_env.py:181
+        p.step_n[e] = step_n;
+        if (p.out.step_n) p.out.step_n[e] = step_n;
+        if (p.out.done) p.out.done[e] = (uint8_t)(step_n >= p.max_step);
+        if (p.out.reward) p.out.reward[e] = (float)reward;
+        if (p.out.reward_f64) p.out.reward_f64[e] = reward;
+        if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
+        if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
+        if (p.out.n_out) p.out.n_out[e] = n_outage;
+    }
+}
+
+// ================================================================================================
+// state construction: ue_mobility.py:433-451 + mobile_env.py:58-59.  `per` threads per env.
+// ================================================================================================
 __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int U = p.U, Gr = p.Gr, per = p.per;  // per = max(U, Gr, B, W64) threads per env
@@ -135,11 +359,178 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The fused env kernel.  BT: compile-time bound on B (4/8/16/32).  MODE: see enum Mode.
-// PLC: path-loss exponent pl_b == 30 (the reference's constant, channel.py:47) => d^-3 by sqrt, no log.
+// ================================================================================================
+// Packed env kernel: U <= 64, EPW = p.epw env instances per wavefront (slots of U lanes), one pass.
+// Host guarantees U >= max(B, Gr) (owner lanes live inside the slot) and EPW*U <= 64.
+// BT: compile-time bound on B.  PLC: pl_b == 30 (channel.py:47) => d^-3 by sqrt.
+// ================================================================================================
 template <int BT, int MODE, bool PLC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const KParams p) {
+    __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int U = p.U, B = p.B, Gr = p.Gr, EPW = p.epw;
+    int slot = 0;
+    for (int s = 1; s < EPW; ++s) slot += (lane >= s * U) ? 1 : 0;
+    const int base = slot * U;   // first lane of my slot
+    const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
+    long long e = ((long long)blockIdx.x * kWavesPerBlock + wave) * EPW + slot;
+    bool live = (lane < EPW * U) && (e < p.N);
+    if (MODE == MODE_RESET) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
+    if (__ballot(live) == 0ull) return;
+    if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
+    const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
+    const double MAXC = (double)p.G;
+    const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
+    int *bs_row = s_bs[wave][slot];
+
+    // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
+    if (MODE != MODE_WARMUP) {
+        const bool bown = live && (ul < B);
+        int bx = 0, by = 0, dig = 0;
+        if (bown) {
+            if (MODE == MODE_RESET) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
+            else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
+        }
+        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+            if (bown) dig = action_digit(p, p.actions[e], p.act_pow[ul]);
+            for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
+                const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
+                int nx, ny;
+                uav_propose(p, xi, yi, di, nx, ny);
+                // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
+                const int dx = xi - bx, dy = yi - by;
+                const bool near = bown && (ul != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
+                const bool collision = (__ballot(near) & slot_mask) != 0ull;
+                if (!collision && bown && ul == i) { bx = nx; by = ny; }
+            }
+        }
+        if (bown) {
+            p.bs_xy[(e * B + ul) * 2] = bx; p.bs_xy[(e * B + ul) * 2 + 1] = by;
+            bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by;
+            if (p.out.bs_xy) { p.out.bs_xy[(e * B + ul) * 2] = bx; p.out.bs_xy[(e * B + ul) * 2 + 1] = by; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // per-env scalars (identical in all lanes of a slot)
+    int agg = 0, deagg = 0;
+    uint32_t tick = p.tick[e];
+    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    int depth = 0, step_n = 0;
+    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    const int u = ul;
+    const long long iu = e * U + (live ? u : 0);
+    int gid = 0;
+    for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
+    const bool gown = live && (ul < Gr);
+
+    double sum_cur = 0.0;
+    int n_outage = 0;
+
+    for (int it = 0; it < n_ticks; ++it) {
+        int ix = 0, iy = 0;
+        if (MODE != MODE_TRACE) {
+            // ---- group owners (ue_mobility.py:458-459) ---------------------------------------------
+            double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
+            const bool aggregating = agg != 0;
+            if (gown) {
+                ogx = p.g_x[e * Gr + ul]; ogy = p.g_y[e * Gr + ul]; ogfl = p.g_fl[e * Gr + ul];
+                ogv = p.g_v[e * Gr + ul]; ogc = p.g_cos[e * Gr + ul]; ogs = p.g_sin[e * Gr + ul];
+                ogx = ogx + ogv * ogc;
+                ogy = ogy + ogv * ogs;
+            }
+            // ---- walker (ue_mobility.py:455-510) ------------------------------------------------------
+            const int src = base + gid;
+            const double gx = __shfl(ogx, src, 64), gy = __shfl(ogy, src, 64);
+            const double gv = __shfl(ogv, src, 64), gc = __shfl(ogc, src, 64), gs = __shfl(ogs, src, 64);
+            double x = 0, y = 0, hu = 0;
+            if (live) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
+            bool c[4];
+            walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
+            c[0] = c[0] && live; c[1] = c[1] && live; c[2] = c[2] && live; c[3] = c[3] && live;
+            uint32_t touched[4] = {0u, 0u, 0u, 0u};  // per slot: groups bounced at x<0, x>MAX, y<0, y>MAX
+            if (__ballot(c[0] || c[1] || c[2] || c[3]) != 0ull) {  // rare, wave-uniform branch
+                for (int g = 0; g < Gr; ++g) {
+                    const bool mine = gid == g;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((__ballot(mine && c[k]) & slot_mask) != 0ull) touched[k] |= 1u << g;
+                }
+            }
+            if (p.inj_theta) { if (live) hu = p.inj_theta[iu]; }                         // new heading (:508)
+            else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
+            ix = (int)x; iy = (int)y;                                                    // .astype(int), mobile_env.py:154-155
+            if (live) {
+                p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu;
+                p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+            }
+            if (gown) {
+                group_finish(p, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
+                p.g_x[e * Gr + ul] = ogx; p.g_y[e * Gr + ul] = ogy; p.g_fl[e * Gr + ul] = ogfl;
+                p.g_v[e * Gr + ul] = ogv; p.g_cos[e * Gr + ul] = ogc; p.g_sin[e * Gr + ul] = ogs;
+            }
+            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }   // :472-473
+            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }               // :486-487
+        } else if (live) {                                                      // mobile_env.py:202-203 (read_trace)
+            ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
+            p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+        }
+
+        if (MODE != MODE_WARMUP) {
+            if (live && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
+            double pg[BT];
+            rx_power<BT, PLC>(p, e, tick, u, live, iu, ix, iy, bs_row, pg);
+            const int best = argmax_pg<BT>(p, pg);
+            const double bestS = sinr_db<BT>(p, pg, best);
+            if (MODE == MODE_RESET) {
+                // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
+                const unsigned long long ob = (__ballot(live && (bestS <= p.out_thresh)) & slot_mask) >> base;
+                if (live) {
+                    if (ul == 0) p.out_bits[e] = ob;
+                    p.serving[iu] = (int8_t)best;
+                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
+                    if (p.out.serving) p.out.serving[iu] = (int8_t)best;
+                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
+                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
+                }
+                sum_cur = slot_sum(live ? bestS : 0.0, ul, U);
+            } else {
+                // UpdateDroneNet, DL part (channel.py:141-174)
+                int serving = 0, r0 = 0, r1 = 0, r2 = 0;
+                if (live) {
+                    serving = p.serving[iu];
+                    r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
+                }
+                const double cur = sinr_db<BT>(p, pg, serving);  // serving UAV BEFORE any handover (:145-146)
+                fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
+                const unsigned long long ob = (__ballot(live && (cur <= p.out_thresh)) & slot_mask) >> base;  // :170
+                const unsigned long long prev = p.out_bits[e];
+                n_outage = __popcll(ob & ~prev);                                           // :171-174 newly outaged
+                if (live) {
+                    if (ul == 0) p.out_bits[e] = ob;                                       // :173
+                    p.serving[iu] = (int8_t)serving;
+                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
+                    p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
+                    p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
+                    if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
+                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
+                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
+                }
+                sum_cur = slot_sum(live ? cur : 0.0, ul, U);
+            }
+        }
+        tick += 1u;
+    }
+    if (live && ul == 0) env_finish<MODE>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+}
+
+// ================================================================================================
+// Multi-pass env kernel: U > 64 (or a slot too narrow for its owner lanes): one env per wavefront, walkers
+// in passes of 64 lanes.  Same helpers, wave-uniform env scalars.
+// ================================================================================================
+template <int BT, int MODE, bool PLC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(const KParams p) {
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -152,42 +543,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
     const int n_pass = (U + 63) >> 6;
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
 
-    // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
     if (MODE != MODE_WARMUP) {
-        int bx = 0, by = 0;
-        if (lane < B) {
-            if (MODE == MODE_RESET) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }  // mobile_env.py:119
+        const bool bown = lane < B;
+        int bx = 0, by = 0, dig = 0;
+        if (bown) {
+            if (MODE == MODE_RESET) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }
             else { bx = p.bs_xy[(e * B + lane) * 2]; by = p.bs_xy[(e * B + lane) * 2 + 1]; }
         }
         if (MODE == MODE_STEP || MODE == MODE_TRACE) {
-            long long a = p.actions[e];
-            int dig = 0;
-            for (int i = B - 1; i >= 0; --i) {  // most-significant digit -> UAV 0
-                const int d = (int)(a % p.n_act);
-                a /= p.n_act;
-                if (lane == i) dig = d;
-            }
-            const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;  // mobile_env.py:45
-            const int s = p.bs_step, sl = 2 * p.bs_step;
-            for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
+            if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane]);
+            for (int i = 0; i < B; ++i) {
                 const int xi = __shfl(bx, i, 64), yi = __shfl(by, i, 64), di = __shfl(dig, i, 64);
-                int nx = xi, ny = yi;
-                if (di == 0) { if (xi + s < xMax) nx = xi + s; }
-                else if (di == 1) { if (xi - s > xMin) nx = xi - s; }
-                else if (di == 2) { if (yi + s < yMax) ny = yi + s; }
-                else if (di == 3) { if (yi - s > yMin) ny = yi - s; }
-                else if (di == 5) { if (xi + sl < xMax) nx = xi + sl; }
-                else if (di == 6) { if (xi - sl > xMin) nx = xi - sl; }
-                else if (di == 7) { if (yi + sl < yMax) ny = yi + sl; }
-                else if (di == 8) { if (yi - sl > yMin) ny = yi - sl; }
-                // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
+                int nx, ny;
+                uav_propose(p, xi, yi, di, nx, ny);
                 const int dx = xi - bx, dy = yi - by;
-                const bool near = (lane < B) && (lane != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
+                const bool near = bown && (lane != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
                 const bool collision = __ballot(near) != 0ull;
                 if (!collision && lane == i) { bx = nx; by = ny; }
             }
         }
-        if (lane < B) {
+        if (bown) {
             p.bs_xy[(e * B + lane) * 2] = bx; p.bs_xy[(e * B + lane) * 2 + 1] = by;
             s_bs[wave][2 * lane] = bx; s_bs[wave][2 * lane + 1] = by;
             if (p.out.bs_xy) { p.out.bs_xy[(e * B + lane) * 2] = bx; p.out.bs_xy[(e * B + lane) * 2 + 1] = by; }
@@ -195,166 +570,72 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
         __builtin_amdgcn_wave_barrier();
     }
 
-    // per-env scalars
     int agg = 0, deagg = 0;
     uint32_t tick = p.tick[e];
     if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
     int depth = 0, step_n = 0;
     if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    const bool gown = lane < Gr;
 
     double sum_cur = 0.0;
     int n_outage = 0;
 
     for (int it = 0; it < n_ticks; ++it) {
-        // ---- group owners: lanes 0..Gr-1 (ue_mobility.py:458-459) -----------------------------
         double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
         const bool aggregating = agg != 0;
         if (MODE != MODE_TRACE) {
-            if (lane < Gr) {
+            if (gown) {
                 ogx = p.g_x[e * Gr + lane]; ogy = p.g_y[e * Gr + lane]; ogfl = p.g_fl[e * Gr + lane];
                 ogv = p.g_v[e * Gr + lane]; ogc = p.g_cos[e * Gr + lane]; ogs = p.g_sin[e * Gr + lane];
                 ogx = ogx + ogv * ogc;
                 ogy = ogy + ogv * ogs;
             }
         }
-        uint32_t touched[4] = {0u, 0u, 0u, 0u};  // groups bounced at x<0, x>MAX, y<0, y>MAX (wave-uniform)
+        uint32_t touched[4] = {0u, 0u, 0u, 0u};
 
         for (int pass = 0; pass < n_pass; ++pass) {
             const int u = pass * 64 + lane;
             const bool act = u < U;
             const long long iu = e * U + (act ? u : 0);
             int ix = 0, iy = 0;
-
             if (MODE != MODE_TRACE) {
-                // ---- one next() of reference_point_group for walker u (ue_mobility.py:455-510) ----
                 int gid = 0;
                 for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
                 const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
                 double x = 0, y = 0, hu = 0;
                 if (act) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
-                double sn, cs;
-                sincospi(2.0 * hu, &sn, &cs);            // theta = 2*pi*u  (:437,508)
-                x = x + p.ue_velocity * cs;               // :455
-                y = y + p.ue_velocity * sn;               // :456
-                if (aggregating) {                        // :461-470
-                    // cos/sin of c_theta = arctan2(g_y - y, g_x - x) (:467) are the normalised components of
-                    // the vector to the group centre; arctan2(0, 0) = 0 gives (1, 0).
-                    const double dxc = gx - x, dyc = gy - y;
-                    const double r2 = dxc * dxc + dyc * dyc;
-                    const double rinv = 1.0 / sqrt(r2);
-                    const double cc = (r2 > 0.0) ? dxc * rinv : 1.0;
-                    const double sc = (r2 > 0.0) ? dyc * rinv : 0.0;
-                    x = x + gv * gc + p.aggregation * cc;
-                    y = y + gv * gs + p.aggregation * sc;
-                } else {                                  // :476-484
-                    x = x + gv * gc;
-                    y = y + gv * gs;
-                }
-                // bounce (:490-505): four ordered tests; each flips the group heading once per group
-                bool c0 = act && (x < 0.0);
-                if (c0) x = -x;
-                bool c1 = act && (x > MAXC);
-                if (c1) x = 2.0 * MAXC - x;
-                bool c2 = act && (y < 0.0);
-                if (c2) y = -y;
-                bool c3 = act && (y > MAXC);
-                if (c3) y = 2.0 * MAXC - y;
-                if (__ballot(c0 || c1 || c2 || c3) != 0ull) {  // rare, wave-uniform branch
+                bool c[4];
+                walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
+                c[0] = c[0] && act; c[1] = c[1] && act; c[2] = c[2] && act; c[3] = c[3] && act;
+                if (__ballot(c[0] || c[1] || c[2] || c[3]) != 0ull) {
                     for (int g = 0; g < Gr; ++g) {
                         const bool mine = gid == g;
-                        if (__ballot(mine && c0)) touched[0] |= 1u << g;
-                        if (__ballot(mine && c1)) touched[1] |= 1u << g;
-                        if (__ballot(mine && c2)) touched[2] |= 1u << g;
-                        if (__ballot(mine && c3)) touched[3] |= 1u << g;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (__ballot(mine && c[k]) != 0ull) touched[k] |= 1u << g;
                     }
                 }
-                // new heading (:508)
                 if (p.inj_theta) { if (act) hu = p.inj_theta[iu]; }
                 else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
-                ix = (int)x; iy = (int)y;                 // .astype(int), mobile_env.py:154-155
+                ix = (int)x; iy = (int)y;
                 if (act) {
                     p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu;
                     p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
                 }
-            } else {
-                if (act) {                                // mobile_env.py:202-203 (read_trace)
-                    ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
-                    p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
-                }
+            } else if (act) {
+                ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
+                p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
             }
-
             if (MODE == MODE_WARMUP) continue;
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
-            // ---- received power of every UAV at walker u (channel.py:220-257), linear domain ---------
-            // The reference goes through dB and back (loss = a + b*log10(d); gain = 10^((ant-loss-f-eq)/10)).
-            // Same value with fewer transcendentals:
-            //     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3, no log at all)
-            //            = k_0  * 10^(-f/10)               otherwise (loss = 0)
-            // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
             double pg[BT];
-#pragma unroll
-            for (int b2 = 0; b2 < BT; b2 += 2) {
-                double f0 = 0.0, f1 = 0.0;
-                if (b2 < B) {
-                    if (p.inj_fading) {
-                        if (act) {
-                            f0 = p.inj_fading[iu * B + b2];
-                            if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
-                        }
-                    } else {  // np.random.normal(mean, sd) (channel.py:240): Box-Muller on Philox uniforms
-                        double u0, u1;
-                        philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
-                        const double r = sqrt(-2.0 * log(1.0 - u0));
-                        double sa, ca;
-                        sincospi(2.0 * u1, &sa, &ca);
-                        f0 = p.shadow_mean + p.shadow_sd * (r * ca);
-                        f1 = p.shadow_mean + p.shadow_sd * (r * sa);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int b = b2 + k;
-                    if (b < BT) {
-                        double g = 0.0;
-                        if (b < B) {
-                            const double f = (k == 0) ? f0 : f1;
-                            const double fx = p.grid_width * (double)(ix - s_bs[wave][2 * b]);       // :221-222
-                            const double fy = p.grid_width * (double)(iy - s_bs[wave][2 * b + 1]);
-                            const double d = sqrt(fx * fx + fy * fy);                                 // :223 (z ignored)
-                            if (PLC) g = p.k_pl * exp2(p.c_exp * f) / (d * d * d);
-                            else g = p.k_pl * exp2(p.c_exp * f - p.pl_exp * log2(d));
-                            if (!(d > p.pl_dis)) g = p.k_0 * exp2(p.c_exp * f);                       // :232-233
-                        }
-                        pg[b] = g;
-                    }
-                }
-            }
-            // best UAV: SINR_b = pg_b / (noise + sum_{j != b} pg_j) is strictly increasing in pg_b (the total
-            // is fixed), so np.argmax over the dB values (:141) == first maximum of pg.
-            int best = 0;
-            double bp = pg[0];
-#pragma unroll
-            for (int b = 1; b < BT; ++b)
-                if (b < B && pg[b] > bp) { bp = pg[b]; best = b; }
-            // 10*log10(S/(N+I)) for one UAV x (:259-268); interference = the OTHER UAVs summed in index order,
-            // never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
-            auto sinr_db = [&](int x) {
-                double interf = 0.0, px = 0.0;
-#pragma unroll
-                for (int j = 0; j < BT; ++j) {
-                    interf += (j != x && j < B) ? pg[j] : 0.0;
-                    px = (j == x) ? pg[j] : px;
-                }
-                return p.db_per_log2 * log2(px / (p.noise_watt + interf));
-            };
-            const double bestS = sinr_db(best);
-
+            rx_power<BT, PLC>(p, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
+            const int best = argmax_pg<BT>(p, pg);
+            const double bestS = sinr_db<BT>(p, pg, best);
             if (MODE == MODE_RESET) {
-                // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
-                const bool is_out = act && (bestS <= p.out_thresh);
-                const unsigned long long ob = __ballot(is_out);
+                const unsigned long long ob = __ballot(act && (bestS <= p.out_thresh));
                 if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
                     p.serving[iu] = (int8_t)best;
@@ -365,26 +646,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
                 }
                 sum_cur += wave_sum(act ? bestS : 0.0);
             } else {
-                // UpdateDroneNet, DL part (channel.py:141-174)
                 int serving = 0, r0 = 0, r1 = 0, r2 = 0;
                 if (act) {
                     serving = p.serving[iu];
                     r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
                 }
-                const double cur = sinr_db(serving);  // SINR of the serving UAV BEFORE any handover (:145-146)
-                bool remain;
-                if (depth == 1) { r1 = best; remain = (r1 == r0); }                       // append (:148-149)
-                else if (depth == 2) { r2 = best; remain = (r1 == r0) && (r2 == r0); }
-                else { r0 = r1; r1 = r2; r2 = best; remain = (r1 == r0) && (r2 == r0); }  // FIFO shift (:150-153)
-                // newest row == best (:156 compares current_BS with bestBS_buf[-1])
-                const bool changed = serving != best;
-                const bool need_ho = remain && changed && (bestS - cur > p.ho_thresh_db);  // :155-159
-                if (need_ho) serving = best;                                               // :162-167
-                const bool is_out = act && (cur <= p.out_thresh);                          // :170
-                const unsigned long long ob = __ballot(is_out);
+                const double cur = sinr_db<BT>(p, pg, serving);
+                fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
+                const unsigned long long ob = __ballot(act && (cur <= p.out_thresh));
                 const unsigned long long prev = p.out_bits[e * p.W64 + pass];
-                n_outage += __popcll(ob & ~prev);                                          // :171-174 newly outaged
-                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;                          // :173
+                n_outage += __popcll(ob & ~prev);
+                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
                     p.serving[iu] = (int8_t)serving;
                     p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
@@ -399,76 +671,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel(const KParams 
         }  // passes
 
         if (MODE != MODE_TRACE) {
-            // ---- group owners: bounce flips, flight length, arrivals (ue_mobility.py:493-521) ----
-            if (lane < Gr) {
-                const uint32_t bit = 1u << lane;
-                if (touched[0] & bit) ogc = -ogc;
-                if (touched[1] & bit) ogc = -ogc;
-                if (touched[2] & bit) ogs = -ogs;
-                if (touched[3] & bit) ogs = -ogs;
-                ogfl = ogfl - ogv;                                    // :513
-                if (ogv > 0.0 && ogfl <= 0.0) {                       // :514
-                    double ut, uf, uv, t1;
-                    if (p.inj_group) {
-                        ut = p.inj_group[(e * Gr + lane) * 3 + 0]; uf = p.inj_group[(e * Gr + lane) * 3 + 1];
-                        uv = p.inj_group[(e * Gr + lane) * 3 + 2];
-                    } else {
-                        philox_u2(p, (uint32_t)e, tick, (uint32_t)lane, DOM_GROUP_A, ut, uf);
-                        philox_u2(p, (uint32_t)e, tick, (uint32_t)lane, DOM_GROUP_B, uv, t1);
-                    }
-                    sincospi(2.0 * ut, &ogs, &ogc);                   // :517-519
-                    ogfl = uf * MAXC;                                 // :520 FL_MAX = max(dimensions)
-                    ogv = uv * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :521
-                }
+            if (gown) {
+                group_finish(p, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
                 p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;
                 p.g_v[e * Gr + lane] = ogv; p.g_cos[e * Gr + lane] = ogc; p.g_sin[e * Gr + lane] = ogs;
             }
-            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }   // :472-473
-            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }               // :486-487
+            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }
+            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }
         }
         tick += 1u;
-        if (MODE == MODE_WARMUP && it + 1 < n_ticks) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }  // ticks
-
-    // ---- per-env scalars and outputs --------------------------------------------------------
-    if (lane == 0) {
-        p.tick[e] = tick;
-        if (MODE != MODE_TRACE) { p.agg[e] = agg; p.deagg[e] = deagg; }
-        if (MODE == MODE_RESET) {
-            p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
-            p.step_n[e] = 0;                                      // mobile_env.py:146
-            const double mean = sum_cur / (double)U;
-            if (p.out.step_n) p.out.step_n[e] = 0;
-            if (p.out.reward) p.out.reward[e] = 0.f;
-            if (p.out.reward_f64) p.out.reward_f64[e] = 0.0;
-            if (p.out.done) p.out.done[e] = 0;
-            if (p.out.n_out) p.out.n_out[e] = 0;
-            if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
-            if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
-        }
-        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
-            if (depth < 3) p.fifo_depth[e] = depth + 1;
-            const double mean = sum_cur / (double)U;              // channel.py:216
-            const double r0 = mean / 20.0;                        // mobile_env.py:165
-            const double r1 = -1.0 * (double)n_outage / (double)U;  // mobile_env.py:167
-            double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
-            if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
-            step_n += 1;                                          // mobile_env.py:181
-            p.step_n[e] = step_n;
-            if (p.out.step_n) p.out.step_n[e] = step_n;
-            if (p.out.done) p.out.done[e] = (uint8_t)(step_n >= p.max_step);  // mobile_env.py:186-187
-            if (p.out.reward) p.out.reward[e] = (float)reward;
-            if (p.out.reward_f64) p.out.reward_f64[e] = reward;
-            if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
-            if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
-            if (p.out.n_out) p.out.n_out[e] = n_outage;
-        }
     }
+    if (lane == 0) env_finish<MODE>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
-// ------------------------------------------------------------------------------------------------
+// ================================================================================================
 // env.state planes: GetGridMap (ue_mobility.py:173-188) + GetCurrentAssociationMap (channel.py:387-409).
 // obs is zero-filled by the caller (hipMemsetAsync); one thread per (env, node); counts add.
+// ================================================================================================
 __global__ __launch_bounds__(256) void obs_scatter_kernel(long long N, int U, int B, int G, const int32_t *bs_xy,
                                                           const int16_t *ue_xy, const int8_t *serving, float *obs) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -85,13 +85,28 @@ def _bits(words, U):
     return np.array([(int(words[u // 64]) >> (u % 64)) & 1 for u in range(U)], bool)
 
 
-@pytest.mark.parametrize("shape", [(4, 20, 100, 64, 96), (4, 40, 200, 16, 40), (16, 200, 100, 8, 24), (7, 33, 64, 8, 24)])
+# (B, U, G, N, T, config overrides).  Every env has its own Philox stream, so a lane / slot mix-up in the packed
+# kernel cannot hide behind identical neighbours.  Kernel variant each row exercises:
+PHILOX_SHAPES = [
+    (4, 20, 100, 64, 96, {}),                  # packed, 3 envs per wavefront, N not a multiple of 3 (tail slot)
+    (4, 20, 100, 65, 24, {}),                  # packed, last wavefront holds 2 of 3 slots
+    (4, 40, 200, 16, 40, {}),                  # packed, 1 env per wavefront, class-default grid
+    (2, 8, 32, 37, 40, {}),                    # packed, 8 envs per wavefront (kMaxEpw), 2 UAVs
+    (7, 33, 64, 8, 24, {}),                    # packed, 1 env per wavefront, BT = 8 with B = 7, ragged groups
+    (16, 200, 100, 8, 24, {}),                 # multi-pass (4 passes), BT = 16, 64-bit action digits
+    (16, 12, 64, 8, 24, {}),                   # multi-pass because U < B (owner lanes would not fit a slot)
+    (4, 20, 100, 32, 40, {"pl_b": 37.6, "pl_a": 15.3}),  # generic path-loss exponent (PLC = false), packed
+    (16, 200, 100, 4, 12, {"pl_b": 37.6}),     # generic path-loss exponent, multi-pass
+]
+
+
+@pytest.mark.parametrize("shape", PHILOX_SHAPES, ids=lambda s: "B%dU%dG%dN%d%s" % (s[0], s[1], s[2], s[3], "gen" if s[5] else ""))
 def test_hip_matches_oracle_on_philox_streams(shape):
     """No injection: device Philox/Box-Muller vs the oracle's, construct + reset + steps + masked reset."""
     torch = _torch()
     from oracle import oracle as O
 
-    B, U, G, N, T = shape
+    B, U, G, N, T, over = shape
     groups = None
     if U % 4:
         groups = [U // 4] * 3 + [U - 3 * (U // 4)]
@@ -102,8 +117,8 @@ def test_hip_matches_oracle_on_philox_streams(shape):
                    for b in range(B)]
     seed, base = 0xC0FFEE1234, 1000
     env = _make(N, nBS=B, nUE=U, grid_n=G, groups=groups, bs_init=bs_init, seed=seed, env_id_base=base,
-                f64_outputs=True)
-    ocfg = O.make_config(B, U, G, groups=groups if groups else [U // 4] * 4, bs_init=bs_init)
+                f64_outputs=True, **over)
+    ocfg = O.make_config(B, U, G, groups=groups if groups else [U // 4] * 4, bs_init=bs_init, **over)
     orc = O.OracleEnv(ocfg, N, seed=seed, env_id_base=base)
     oo = orc.construct()
     rs = np.random.RandomState(7)
