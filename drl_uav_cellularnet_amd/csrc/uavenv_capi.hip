@@ -27,6 +27,7 @@ struct uavenv {
     char *blob;
     int32_t *bs_init_dev;
     long long *act_pow_dev;
+    int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
 };
@@ -168,6 +169,19 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     for (int b = cfg->n_bs - 1; b >= 0; --b) { act_pow[b] = pw; pw *= cfg->n_act; }
     const long long n_joint = pw;  // n_act^B = action_space_dim (mobile_env.py:104)
     (void)hipMemcpy(h->act_pow_dev, act_pow, sizeof(act_pow), hipMemcpyHostToDevice);
+    {   // group of every walker (ue_mobility.py:417-426 g_ref), padded so that idle lanes read in range
+        const size_t n_gid = U < 64 ? 64 : U;
+        std::string gid(n_gid, '\0');
+        size_t w = 0;
+        for (int g = 0; g < cfg->n_groups; ++g)
+            for (int i = 0; i < cfg->group_size[g]; ++i) gid[w++] = (char)g;
+        e = hipMalloc((void **)&h->gid_dev, n_gid);
+        if (e != hipSuccess) {
+            (void)hipFree(h->blob); (void)hipFree(h->bs_init_dev); (void)hipFree(h->act_pow_dev); delete h;
+            return fail(UAVENV_E_NOMEM, "create: hipMalloc gid table");
+        }
+        (void)hipMemcpy(h->gid_dev, gid.data(), n_gid, hipMemcpyHostToDevice);
+    }
 
     KParams &k = h->kp;
     std::memset(&k, 0, sizeof(k));
@@ -204,6 +218,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.step_n = (int32_t *)(b + L.step_n); k.ue_xy = (int16_t *)(b + L.ue_xy);
     k.bs_init = h->bs_init_dev;
     k.act_pow = h->act_pow_dev;
+    k.gid_of_u = h->gid_dev;
     k.act32 = (n_joint <= 0xFFFFFFFFll) ? 1 : 0;  // 32-bit digit extraction when every joint action fits
     // Packed kernel: floor(64/U) env instances per wavefront; needs the group / UAV owner lanes inside a slot.
     h->packed = (cfg->n_ue <= 64) && (cfg->n_ue >= cfg->n_bs) && (cfg->n_ue >= cfg->n_groups);
@@ -222,6 +237,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->blob);
     (void)hipFree(h->bs_init_dev);
     (void)hipFree(h->act_pow_dev);
+    (void)hipFree(h->gid_dev);
     delete h;
 }
 
@@ -252,21 +268,47 @@ extern "C" int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *strea
     return UAVENV_OK;
 }
 
+// FAST kernels: no injected draws, all nine standard outputs present, no float64 copies (see UAV_OUT in
+// uavenv_kernels.h).  Anything else runs the checked variant of the same kernel.
+static bool call_is_fast(const KParams &p) {
+    const OutPtrs &o = p.out;
+    return !p.inj_theta && !p.inj_group && !p.inj_fading && o.reward && o.done && o.mean_sinr && o.n_out && o.ue_xy &&
+           o.bs_xy && o.serving && o.cur_sinr && o.step_n && !o.cur_sinr_f64 && !o.mean_sinr_f64 && !o.reward_f64;
+}
+
 template <int MODE>
 static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
     const long long waves = (p.N + p.epw - 1) / p.epw;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
-#define UAVENV_LAUNCH(BT_)                                                                                     \
-    do {                                                                                                       \
-        if (h->packed) {                                                                                       \
-            if (h->plc) hipLaunchKernelGGL((env_kernel_packed<BT_, MODE, true>), dim3(grid), blk, 0, s, p);    \
-            else hipLaunchKernelGGL((env_kernel_packed<BT_, MODE, false>), dim3(grid), blk, 0, s, p);          \
-        } else {                                                                                               \
-            if (h->plc) hipLaunchKernelGGL((env_kernel_multipass<BT_, MODE, true>), dim3(grid), blk, 0, s, p); \
-            else hipLaunchKernelGGL((env_kernel_multipass<BT_, MODE, false>), dim3(grid), blk, 0, s, p);       \
-        }                                                                                                      \
+    if (MODE == MODE_WARMUP) {
+        // mobility only: independent of B / path loss, so one instantiation per kernel family
+        const bool fast = !p.inj_theta && !p.inj_group;
+        if (h->packed) {
+            if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, p);
+            else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, p);
+        } else {
+            hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true>), dim3(grid), blk, 0, s, p);
+        }
+        HIP_TRY(hipGetLastError());
+        return UAVENV_OK;
+    }
+    constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
+    const bool fast = call_is_fast(p);
+#define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
+    do {                                                                                                         \
+        if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true>), dim3(grid), blk, 0, s, p);          \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false>), dim3(grid), blk, 0, s, p);              \
+    } while (0)
+#define UAVENV_LAUNCH(BT_)                                                                                       \
+    do {                                                                                                         \
+        if (h->packed) {                                                                                         \
+            if (h->plc) UAVENV_LAUNCH_PK(BT_, true); else UAVENV_LAUNCH_PK(BT_, false);                          \
+        } else {                                                                                                 \
+            if (h->plc) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true>), dim3(grid), blk, 0, s, p);      \
+            else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false>), dim3(grid), blk, 0, s, p);            \
+        }                                                                                                        \
     } while (0)
     switch (h->bt) {
         case 4: UAVENV_LAUNCH(4); break;
@@ -275,6 +317,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
         default: UAVENV_LAUNCH(32); break;
     }
 #undef UAVENV_LAUNCH
+#undef UAVENV_LAUNCH_PK
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

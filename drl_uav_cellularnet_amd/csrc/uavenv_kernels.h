@@ -33,6 +33,14 @@ constexpr int kMaxEpw = 8;  // env instances per wavefront (packed kernel)
 
 enum Mode : int { MODE_WARMUP = 0, MODE_RESET = 1, MODE_STEP = 2, MODE_TRACE = 3 };
 
+// FAST kernels are launched when the call injects no randomness, passes all nine standard outputs and no
+// float64 copies (what BatchedMobiEnv.step does): every optional-pointer test folds away at compile time.
+// Why it matters: each runtime test was a scalar kernarg load + s_waitcnt lgkmcnt(0) + branch; the r01_v3
+// profile has 59 such drains per wave = 47 % of the wave cycles (profiles/r01_v3_packed_sq_counters.txt).
+#define UAV_INJ(ptr) (!FAST && (ptr) != nullptr)     /* injected draws present            */
+#define UAV_OUT(ptr) (FAST || (ptr) != nullptr)      /* standard output requested         */
+#define UAV_OUT64(ptr) (!FAST && (ptr) != nullptr)   /* optional float64 copy requested   */
+
 struct OutPtrs {
     float *reward; uint8_t *done; float *mean_sinr; int32_t *n_out;
     int16_t *ue_xy; int32_t *bs_xy; int8_t *serving; float *cur_sinr; int32_t *step_n;
@@ -55,6 +63,7 @@ struct KParams {
     unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
     const int32_t *bs_init;      // [B,2] device copy of the start cells
     const long long *act_pow;    // [B]   n_act^(B-1-b): joint action -> digit of UAV b (most significant first)
+    const int8_t *gid_of_u;      // [U]   RPGM group of walker u (from group_size)
     // per-call inputs
     const double *inj_theta, *inj_group, *inj_fading;
     const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
@@ -154,6 +163,7 @@ __device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, 
 }
 
 // Group owner, end of tick (ue_mobility.py:493-521): bounce flips, remaining flight length, arrival redraw.
+template <bool FAST>
 __device__ __forceinline__ void group_finish(const KParams &p, long long e, int g, uint32_t tick, const uint32_t touched[4],
                                              double MAXC, double &ogfl, double &ogv, double &ogc, double &ogs) {
     const uint32_t bit = 1u << g;
@@ -164,7 +174,7 @@ __device__ __forceinline__ void group_finish(const KParams &p, long long e, int 
     ogfl = ogfl - ogv;                                    // :513
     if (ogv > 0.0 && ogfl <= 0.0) {                       // :514
         double ut, uf, uv, t1;
-        if (p.inj_group) {
+        if (UAV_INJ(p.inj_group)) {
             ut = p.inj_group[(e * p.Gr + g) * 3 + 0]; uf = p.inj_group[(e * p.Gr + g) * 3 + 1];
             uv = p.inj_group[(e * p.Gr + g) * 3 + 2];
         } else {
@@ -185,7 +195,7 @@ __device__ __forceinline__ void group_finish(const KParams &p, long long e, int 
 // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
 // bs: this env's UAV cells in LDS ([2*B] ints).  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
 // Philox uniforms (one call -> two UAVs), replacing np.random.normal (channel.py:240).
-template <int BT, bool PLC>
+template <int BT, bool PLC, bool FAST>
 __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t tick, int u, bool act, long long iu,
                                          int ix, int iy, const int *bs, double pg[BT]) {
     const int B = p.B;
@@ -193,7 +203,7 @@ __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t
     for (int b2 = 0; b2 < BT; b2 += 2) {
         double f0 = 0.0, f1 = 0.0;
         if (b2 < B) {
-            if (p.inj_fading) {
+            if (UAV_INJ(p.inj_fading)) {
                 if (act) {
                     f0 = p.inj_fading[iu * B + b2];
                     if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
@@ -265,7 +275,7 @@ __device__ __forceinline__ void fifo_handover(const KParams &p, int depth, int b
 }
 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
-template <int MODE>
+template <int MODE, bool FAST>
 __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32_t tick, int agg, int deagg, int depth,
                                            int step_n, double sum_cur, int n_outage) {
     p.tick[e] = tick;
@@ -274,13 +284,13 @@ __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32
         p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
         p.step_n[e] = 0;                                      // mobile_env.py:146
         const double mean = sum_cur / (double)p.U;
-        if (p.out.step_n) p.out.step_n[e] = 0;
-        if (p.out.reward) p.out.reward[e] = 0.f;
-        if (p.out.reward_f64) p.out.reward_f64[e] = 0.0;
-        if (p.out.done) p.out.done[e] = 0;
-        if (p.out.n_out) p.out.n_out[e] = 0;
-        if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
-        if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
+        if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = 0;
+        if (UAV_OUT(p.out.reward)) p.out.reward[e] = 0.f;
+        if (UAV_OUT64(p.out.reward_f64)) p.out.reward_f64[e] = 0.0;
+        if (UAV_OUT(p.out.done)) p.out.done[e] = 0;
+        if (UAV_OUT(p.out.n_out)) p.out.n_out[e] = 0;
+        if (UAV_OUT(p.out.mean_sinr)) p.out.mean_sinr[e] = (float)mean;
+        if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
     }
     if (MODE == MODE_STEP || MODE == MODE_TRACE) {
         if (depth < 3) p.fifo_depth[e] = depth + 1;
@@ -291,13 +301,13 @@ __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
         p.step_n[e] = step_n;
-        if (p.out.step_n) p.out.step_n[e] = step_n;
-        if (p.out.done) p.out.done[e] = (uint8_t)(step_n >= p.max_step);
-        if (p.out.reward) p.out.reward[e] = (float)reward;
-        if (p.out.reward_f64) p.out.reward_f64[e] = reward;
-        if (p.out.mean_sinr) p.out.mean_sinr[e] = (float)mean;
-        if (p.out.mean_sinr_f64) p.out.mean_sinr_f64[e] = mean;
-        if (p.out.n_out) p.out.n_out[e] = n_outage;
+        if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = step_n;
+        if (UAV_OUT(p.out.done)) p.out.done[e] = (uint8_t)(step_n >= p.max_step);
+        if (UAV_OUT(p.out.reward)) p.out.reward[e] = (float)reward;
+        if (UAV_OUT64(p.out.reward_f64)) p.out.reward_f64[e] = reward;
+        if (UAV_OUT(p.out.mean_sinr)) p.out.mean_sinr[e] = (float)mean;
+        if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
+        if (UAV_OUT(p.out.n_out)) p.out.n_out[e] = n_outage;
     }
 }
 
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // Host guarantees U >= max(B, Gr) (owner lanes live inside the slot) and EPW*U <= 64.
 // BT: compile-time bound on B.  PLC: pl_b == 30 (channel.py:47) => d^-3 by sqrt.
 // ================================================================================================
-template <int BT, int MODE, bool PLC>
+template <int BT, int MODE, bool PLC, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const KParams p) {
     __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
     const int lane = threadIdx.x & 63;
@@ -383,17 +393,57 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     const double MAXC = (double)p.G;
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
     int *bs_row = s_bs[wave][slot];
+    const int u = ul;
+    const long long iu = e * U + (live ? u : 0);
+    const bool head = live && (ul == 0);                             // writes the per-env scalars
+    const bool bown = (MODE != MODE_WARMUP) && live && (ul < B);     // this lane owns UAV `ul`
+    const bool gown = (MODE != MODE_TRACE) && live && (ul < Gr);     // this lane owns RPGM group `ul`
 
+    // ================= load phase: every global read of the launch, issued before any dependent work ======
+    int bx = 0, by = 0;
+    long long act = 0, apw = 1;
+    if (bown) {
+        if (MODE == MODE_RESET) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
+        else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
+        if (MODE == MODE_STEP || MODE == MODE_TRACE) { act = p.actions[e]; apw = p.act_pow[ul]; }
+    }
+    uint32_t tick = p.tick[e];
+    int agg = 0, deagg = 0;
+    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    int depth = 0, step_n = 0;
+    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
+    if (gown) {
+        ogx = p.g_x[e * Gr + ul]; ogy = p.g_y[e * Gr + ul]; ogfl = p.g_fl[e * Gr + ul];
+        ogv = p.g_v[e * Gr + ul]; ogc = p.g_cos[e * Gr + ul]; ogs = p.g_sin[e * Gr + ul];
+    }
+    double x = 0, y = 0, hu = 0, hu_inj = 0;
+    int ix = 0, iy = 0, gid = 0;
+    if (MODE != MODE_TRACE) {
+        gid = p.gid_of_u[u];                                      // table padded to >= 64 entries: dead lanes have u < 64
+        if (live) {
+            x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu];
+            if (UAV_INJ(p.inj_theta)) hu_inj = p.inj_theta[iu];   // injected draws cover exactly one tick
+        }
+    } else if (live) {                                            // mobile_env.py:202-203 (read_trace)
+        ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
+    }
+    int serving = 0, r0 = 0, r1 = 0, r2 = 0;
+    unsigned long long prev_out = 0ull;
+    if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+        if (live) {
+            serving = p.serving[iu];
+            r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
+        }
+        prev_out = p.out_bits[e];
+    }
+
+    // ================= compute ===============================================================================
     // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
     if (MODE != MODE_WARMUP) {
-        const bool bown = live && (ul < B);
-        int bx = 0, by = 0, dig = 0;
-        if (bown) {
-            if (MODE == MODE_RESET) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
-            else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
-        }
         if (MODE == MODE_STEP || MODE == MODE_TRACE) {
-            if (bown) dig = action_digit(p, p.actions[e], p.act_pow[ul]);
+            int dig = 0;
+            if (bown) dig = action_digit(p, act, apw);
             for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
                 const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
                 int nx, ny;
@@ -405,49 +455,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
                 if (!collision && bown && ul == i) { bx = nx; by = ny; }
             }
         }
-        if (bown) {
-            p.bs_xy[(e * B + ul) * 2] = bx; p.bs_xy[(e * B + ul) * 2 + 1] = by;
-            bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by;
-            if (p.out.bs_xy) { p.out.bs_xy[(e * B + ul) * 2] = bx; p.out.bs_xy[(e * B + ul) * 2 + 1] = by; }
-        }
+        if (bown) { bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by; }   // UAV cells staged in LDS for rx_power
         __builtin_amdgcn_wave_barrier();
     }
 
-    // per-env scalars (identical in all lanes of a slot)
-    int agg = 0, deagg = 0;
-    uint32_t tick = p.tick[e];
-    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
-    int depth = 0, step_n = 0;
-    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
-    const int u = ul;
-    const long long iu = e * U + (live ? u : 0);
-    int gid = 0;
-    for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
-    const bool gown = live && (ul < Gr);
-
-    double sum_cur = 0.0;
-    int n_outage = 0;
-
+    // ---- mobility: n_ticks x next(self.mm); walker and group state stay in registers across ticks ----
     for (int it = 0; it < n_ticks; ++it) {
-        int ix = 0, iy = 0;
         if (MODE != MODE_TRACE) {
-            // ---- group owners (ue_mobility.py:458-459) ---------------------------------------------
-            double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
             const bool aggregating = agg != 0;
-            if (gown) {
-                ogx = p.g_x[e * Gr + ul]; ogy = p.g_y[e * Gr + ul]; ogfl = p.g_fl[e * Gr + ul];
-                ogv = p.g_v[e * Gr + ul]; ogc = p.g_cos[e * Gr + ul]; ogs = p.g_sin[e * Gr + ul];
+            if (gown) {                                          // ue_mobility.py:458-459
                 ogx = ogx + ogv * ogc;
                 ogy = ogy + ogv * ogs;
             }
-            // ---- walker (ue_mobility.py:455-510) ------------------------------------------------------
             const int src = base + gid;
             const double gx = __shfl(ogx, src, 64), gy = __shfl(ogy, src, 64);
             const double gv = __shfl(ogv, src, 64), gc = __shfl(ogc, src, 64), gs = __shfl(ogs, src, 64);
-            double x = 0, y = 0, hu = 0;
-            if (live) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
             bool c[4];
-            walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
+            walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);   // ue_mobility.py:455-505
             c[0] = c[0] && live; c[1] = c[1] && live; c[2] = c[2] && live; c[3] = c[3] && live;
             uint32_t touched[4] = {0u, 0u, 0u, 0u};  // per slot: groups bounced at x<0, x>MAX, y<0, y>MAX
             if (__ballot(c[0] || c[1] || c[2] || c[3]) != 0ull) {  // rare, wave-uniform branch
@@ -458,71 +482,66 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
                         if ((__ballot(mine && c[k]) & slot_mask) != 0ull) touched[k] |= 1u << g;
                 }
             }
-            if (p.inj_theta) { if (live) hu = p.inj_theta[iu]; }                         // new heading (:508)
+            if (UAV_INJ(p.inj_theta)) hu = hu_inj;                                       // new heading (:508)
             else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
-            ix = (int)x; iy = (int)y;                                                    // .astype(int), mobile_env.py:154-155
-            if (live) {
-                p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu;
-                p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
-            }
-            if (gown) {
-                group_finish(p, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
-                p.g_x[e * Gr + ul] = ogx; p.g_y[e * Gr + ul] = ogy; p.g_fl[e * Gr + ul] = ogfl;
-                p.g_v[e * Gr + ul] = ogv; p.g_cos[e * Gr + ul] = ogc; p.g_sin[e * Gr + ul] = ogs;
-            }
-            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }   // :472-473
-            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }               // :486-487
-        } else if (live) {                                                      // mobile_env.py:202-203 (read_trace)
-            ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
-            p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
-        }
-
-        if (MODE != MODE_WARMUP) {
-            if (live && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
-            double pg[BT];
-            rx_power<BT, PLC>(p, e, tick, u, live, iu, ix, iy, bs_row, pg);
-            const int best = argmax_pg<BT>(p, pg);
-            const double bestS = sinr_db<BT>(p, pg, best);
-            if (MODE == MODE_RESET) {
-                // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
-                const unsigned long long ob = (__ballot(live && (bestS <= p.out_thresh)) & slot_mask) >> base;
-                if (live) {
-                    if (ul == 0) p.out_bits[e] = ob;
-                    p.serving[iu] = (int8_t)best;
-                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
-                    if (p.out.serving) p.out.serving[iu] = (int8_t)best;
-                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
-                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
-                }
-                sum_cur = slot_sum(live ? bestS : 0.0, ul, U);
-            } else {
-                // UpdateDroneNet, DL part (channel.py:141-174)
-                int serving = 0, r0 = 0, r1 = 0, r2 = 0;
-                if (live) {
-                    serving = p.serving[iu];
-                    r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
-                }
-                const double cur = sinr_db<BT>(p, pg, serving);  // serving UAV BEFORE any handover (:145-146)
-                fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
-                const unsigned long long ob = (__ballot(live && (cur <= p.out_thresh)) & slot_mask) >> base;  // :170
-                const unsigned long long prev = p.out_bits[e];
-                n_outage = __popcll(ob & ~prev);                                           // :171-174 newly outaged
-                if (live) {
-                    if (ul == 0) p.out_bits[e] = ob;                                       // :173
-                    p.serving[iu] = (int8_t)serving;
-                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-                    p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
-                    p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
-                    if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
-                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
-                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
-                }
-                sum_cur = slot_sum(live ? cur : 0.0, ul, U);
-            }
+            if (gown) group_finish<FAST>(p, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);   // :493-521
+            if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }            // :472-473
+            else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }                        // :486-487
         }
         tick += 1u;
     }
-    if (live && ul == 0) env_finish<MODE>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (MODE != MODE_TRACE) { ix = (int)x; iy = (int)y; }                                // .astype(int), mobile_env.py:154-155
+
+    // ---- channel update (one per reset / step; Philox time = the tick just executed) ------------------
+    double sum_cur = 0.0, cur = 0.0;
+    int n_outage = 0;
+    unsigned long long ob = 0ull;
+    if (MODE != MODE_WARMUP) {
+        double pg[BT];
+        rx_power<BT, PLC, FAST>(p, e, tick - 1u, u, live, iu, ix, iy, bs_row, pg);
+        const int best = argmax_pg<BT>(p, pg);
+        const double bestS = sinr_db<BT>(p, pg, best);
+        if (MODE == MODE_RESET) {
+            // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
+            cur = bestS;
+            serving = best;
+            r0 = best;                                                                   // bestBS_buf = [current_BS]
+        } else {
+            // UpdateDroneNet, DL part (channel.py:141-174)
+            cur = sinr_db<BT>(p, pg, serving);       // serving UAV BEFORE any handover (:145-146)
+            fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
+        }
+        ob = (__ballot(live && (cur <= p.out_thresh)) & slot_mask) >> base;               // :116 / :170
+        if (MODE != MODE_RESET) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
+        sum_cur = slot_sum(live ? cur : 0.0, ul, U);
+    }
+
+    // ================= store phase: state, then outputs ==========================================================
+    if (live) {
+        if (MODE != MODE_TRACE) { p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu; }
+        p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+        if (MODE != MODE_WARMUP) {
+            p.serving[iu] = (int8_t)serving;
+            p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
+            if (MODE != MODE_RESET) { p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
+            if (UAV_OUT(p.out.ue_xy)) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
+            if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
+            if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
+            if (UAV_OUT64(p.out.cur_sinr_f64)) p.out.cur_sinr_f64[iu] = cur;
+        }
+    }
+    if (gown) {
+        p.g_x[e * Gr + ul] = ogx; p.g_y[e * Gr + ul] = ogy; p.g_fl[e * Gr + ul] = ogfl;
+        p.g_v[e * Gr + ul] = ogv; p.g_cos[e * Gr + ul] = ogc; p.g_sin[e * Gr + ul] = ogs;
+    }
+    if (bown) {
+        p.bs_xy[(e * B + ul) * 2] = bx; p.bs_xy[(e * B + ul) * 2 + 1] = by;
+        if (UAV_OUT(p.out.bs_xy)) { p.out.bs_xy[(e * B + ul) * 2] = bx; p.out.bs_xy[(e * B + ul) * 2 + 1] = by; }
+    }
+    if (head) {
+        if (MODE != MODE_WARMUP) p.out_bits[e] = ob;                                     // :116 / :173
+        env_finish<MODE, FAST>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    }
 }
 
 // ================================================================================================
@@ -531,6 +550,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
 // ================================================================================================
 template <int BT, int MODE, bool PLC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(const KParams p) {
+    constexpr bool FAST = false;  // U > 64: per-wave work is large, the checked path is kept
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
             double pg[BT];
-            rx_power<BT, PLC>(p, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
+            rx_power<BT, PLC, FAST>(p, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
             const int best = argmax_pg<BT>(p, pg);
             const double bestS = sinr_db<BT>(p, pg, best);
             if (MODE == MODE_RESET) {
@@ -672,7 +692,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
         if (MODE != MODE_TRACE) {
             if (gown) {
-                group_finish(p, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
+                group_finish<FAST>(p, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
                 p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;
                 p.g_v[e * Gr + lane] = ogv; p.g_cos[e * Gr + lane] = ogc; p.g_sin[e * Gr + lane] = ogs;
             }
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         }
         tick += 1u;
     }
-    if (lane == 0) env_finish<MODE>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (lane == 0) env_finish<MODE, FAST>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
 // ================================================================================================
