@@ -51,7 +51,8 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_step", "uavenv_step_trace", "uavenv_obs_dense",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_trace",
+           "uavenv_obs_dense",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10")
 
 _lib = None
@@ -85,6 +86,7 @@ def load():
     lib.uavenv_init.argtypes = [_P, C.POINTER(UavEnvInitInject), _P]
     lib.uavenv_warmup.argtypes = [_P, C.c_int, C.POINTER(UavEnvInject), _P]
     lib.uavenv_reset.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_reset_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_obs_dense.argtypes = [_P, _P, _P]

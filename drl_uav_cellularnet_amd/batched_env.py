@@ -158,6 +158,24 @@ class BatchedMobiEnv:
                                            self._stream()))
         return self.observation()
 
+    def reset_trace(self, ue_xy, mask=None, fading=None):
+        """reset() / constructor tail with mobility_model == 'read_trace' (mobile_env.py:85-89,128-131):
+        UE cells = ``ue_xy`` [N, U, 2] (row 0 of the trace), no mobility tick."""
+        x = torch.as_tensor(ue_xy).to(device=self.device, dtype=torch.int16).contiguous()
+        if x.numel() != self.n_envs * self.nUE * 2:
+            raise ValueError("ue_xy must be [N, U, 2]")
+        self._trace_keep = x
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.n_envs:
+                raise ValueError("mask must have n_envs elements")
+            self._mask_keep = mask
+            mptr = mask.data_ptr()
+        _capi.check(self._lib.uavenv_reset_trace(self._h, mptr, x.data_ptr(), self._inject(None, None, fading),
+                                                 self._out_ref, self._stream()))
+        return self.observation()
+
     def step(self, actions, theta_u=None, group_u=None, fading=None):
         """MobiEnvironment.step (mobile_env.py:150-194): returns (obs, reward, done, info).
 

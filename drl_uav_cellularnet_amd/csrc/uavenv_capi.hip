@@ -378,6 +378,16 @@ extern "C" int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const 
     return launch_env<MODE_TRACE>(h, p, (hipStream_t)stream);
 }
 
+extern "C" int uavenv_reset_trace(uavenv_t *h, const uint8_t *mask_dev, const int16_t *ue_xy_in_dev,
+                                  const UavEnvInject *inj, const UavEnvOut *out, void *stream) {
+    if (!h || !ue_xy_in_dev) return fail(UAVENV_E_INVALID, "reset_trace: null handle or trace");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, inj, out);
+    p.mask = mask_dev; p.trace_xy = ue_xy_in_dev; p.n_ticks = 1;
+    return launch_env<MODE_RESET_TRACE>(h, p, (hipStream_t)stream);
+}
+
 extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense: null handle or buffer");
     DeviceGuard guard(h->device);

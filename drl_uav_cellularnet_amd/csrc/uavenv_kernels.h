@@ -31,7 +31,16 @@ constexpr int kMaxGroups = 16;
 constexpr int kMaxBs = 32;
 constexpr int kMaxEpw = 8;  // env instances per wavefront (packed kernel)
 
-enum Mode : int { MODE_WARMUP = 0, MODE_RESET = 1, MODE_STEP = 2, MODE_TRACE = 3 };
+enum Mode : int {
+    MODE_WARMUP = 0,       // mobility ticks only                                   (mobile_env.py:77-79)
+    MODE_RESET = 1,        // UAVs to start cells + one tick + LTEChannel.reset     (mobile_env.py:115-148, "group")
+    MODE_STEP = 2,         // tick + BS_move + UpdateDroneNet                       (mobile_env.py:150-194)
+    MODE_TRACE = 3,        // step_test, UE cells from a trace, no tick             (mobile_env.py:196-233, "read_trace")
+    MODE_RESET_TRACE = 4   // reset, UE cells from a trace, no tick                 (mobile_env.py:128-131)
+};
+__host__ __device__ constexpr bool is_reset(int m) { return m == MODE_RESET || m == MODE_RESET_TRACE; }
+__host__ __device__ constexpr bool is_step(int m) { return m == MODE_STEP || m == MODE_TRACE; }
+__host__ __device__ constexpr bool has_mobility(int m) { return m == MODE_WARMUP || m == MODE_RESET || m == MODE_STEP; }
 
 // FAST kernels are launched when the call injects no randomness, passes all nine standard outputs and no
 // float64 copies (what BatchedMobiEnv.step does): every optional-pointer test folds away at compile time.
@@ -279,8 +288,8 @@ template <int MODE, bool FAST>
 __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32_t tick, int agg, int deagg, int depth,
                                            int step_n, double sum_cur, int n_outage) {
     p.tick[e] = tick;
-    if (MODE != MODE_TRACE) { p.agg[e] = agg; p.deagg[e] = deagg; }
-    if (MODE == MODE_RESET) {
+    if (has_mobility(MODE)) { p.agg[e] = agg; p.deagg[e] = deagg; }
+    if (is_reset(MODE)) {
         p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
         p.step_n[e] = 0;                                      // mobile_env.py:146
         const double mean = sum_cur / (double)p.U;
@@ -292,7 +301,7 @@ __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32
         if (UAV_OUT(p.out.mean_sinr)) p.out.mean_sinr[e] = (float)mean;
         if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
     }
-    if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+    if (is_step(MODE)) {
         if (depth < 3) p.fifo_depth[e] = depth + 1;
         const double mean = sum_cur / (double)p.U;            // channel.py:216
         const double r0 = mean / 20.0;                        // mobile_env.py:165
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
     long long e = ((long long)blockIdx.x * kWavesPerBlock + wave) * EPW + slot;
     bool live = (lane < EPW * U) && (e < p.N);
-    if (MODE == MODE_RESET) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
+    if (is_reset(MODE)) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
     if (__ballot(live) == 0ull) return;
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
     const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
@@ -397,21 +406,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     const long long iu = e * U + (live ? u : 0);
     const bool head = live && (ul == 0);                             // writes the per-env scalars
     const bool bown = (MODE != MODE_WARMUP) && live && (ul < B);     // this lane owns UAV `ul`
-    const bool gown = (MODE != MODE_TRACE) && live && (ul < Gr);     // this lane owns RPGM group `ul`
+    const bool gown = (has_mobility(MODE)) && live && (ul < Gr);     // this lane owns RPGM group `ul`
 
     // ================= load phase: every global read of the launch, issued before any dependent work ======
     int bx = 0, by = 0;
     long long act = 0, apw = 1;
     if (bown) {
-        if (MODE == MODE_RESET) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
+        if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
         else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
-        if (MODE == MODE_STEP || MODE == MODE_TRACE) { act = p.actions[e]; apw = p.act_pow[ul]; }
+        if (is_step(MODE)) { act = p.actions[e]; apw = p.act_pow[ul]; }
     }
     uint32_t tick = p.tick[e];
     int agg = 0, deagg = 0;
-    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    if (has_mobility(MODE)) { agg = p.agg[e]; deagg = p.deagg[e]; }
     int depth = 0, step_n = 0;
-    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    if (is_step(MODE)) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
         ogx = p.g_x[e * Gr + ul]; ogy = p.g_y[e * Gr + ul]; ogfl = p.g_fl[e * Gr + ul];
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     }
     double x = 0, y = 0, hu = 0, hu_inj = 0;
     int ix = 0, iy = 0, gid = 0;
-    if (MODE != MODE_TRACE) {
+    if (has_mobility(MODE)) {
         gid = p.gid_of_u[u];                                      // table padded to >= 64 entries: dead lanes have u < 64
         if (live) {
             x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu];
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     }
     int serving = 0, r0 = 0, r1 = 0, r2 = 0;
     unsigned long long prev_out = 0ull;
-    if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+    if (is_step(MODE)) {
         if (live) {
             serving = p.serving[iu];
             r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     // ================= compute ===============================================================================
     // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
     if (MODE != MODE_WARMUP) {
-        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+        if (is_step(MODE)) {
             int dig = 0;
             if (bown) dig = action_digit(p, act, apw);
             for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
 
     // ---- mobility: n_ticks x next(self.mm); walker and group state stay in registers across ticks ----
     for (int it = 0; it < n_ticks; ++it) {
-        if (MODE != MODE_TRACE) {
+        if (has_mobility(MODE)) {
             const bool aggregating = agg != 0;
             if (gown) {                                          // ue_mobility.py:458-459
                 ogx = ogx + ogv * ogc;
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         }
         tick += 1u;
     }
-    if (MODE != MODE_TRACE) { ix = (int)x; iy = (int)y; }                                // .astype(int), mobile_env.py:154-155
+    if (has_mobility(MODE)) { ix = (int)x; iy = (int)y; }                                // .astype(int), mobile_env.py:154-155
 
     // ---- channel update (one per reset / step; Philox time = the tick just executed) ------------------
     double sum_cur = 0.0, cur = 0.0;
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         rx_power<BT, PLC, FAST>(p, e, tick - 1u, u, live, iu, ix, iy, bs_row, pg);
         const int best = argmax_pg<BT>(p, pg);
         const double bestS = sinr_db<BT>(p, pg, best);
-        if (MODE == MODE_RESET) {
+        if (is_reset(MODE)) {
             // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
             cur = bestS;
             serving = best;
@@ -512,18 +521,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
             fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
         }
         ob = (__ballot(live && (cur <= p.out_thresh)) & slot_mask) >> base;               // :116 / :170
-        if (MODE != MODE_RESET) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
+        if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
         sum_cur = slot_sum(live ? cur : 0.0, ul, U);
     }
 
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
-        if (MODE != MODE_TRACE) { p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu; }
+        if (has_mobility(MODE)) { p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu; }
         p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
         if (MODE != MODE_WARMUP) {
             p.serving[iu] = (int8_t)serving;
             p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-            if (MODE != MODE_RESET) { p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
+            if (!is_reset(MODE)) { p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
             if (UAV_OUT(p.out.ue_xy)) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
             if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
             if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
     if (e >= p.N) return;
-    if (MODE == MODE_RESET) { if (p.mask != nullptr && p.mask[e] == 0) return; }
+    if (is_reset(MODE)) { if (p.mask != nullptr && p.mask[e] == 0) return; }
 
     const int U = p.U, B = p.B, Gr = p.Gr;
     const double MAXC = (double)p.G;
@@ -567,10 +576,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         const bool bown = lane < B;
         int bx = 0, by = 0, dig = 0;
         if (bown) {
-            if (MODE == MODE_RESET) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }
+            if (is_reset(MODE)) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }
             else { bx = p.bs_xy[(e * B + lane) * 2]; by = p.bs_xy[(e * B + lane) * 2 + 1]; }
         }
-        if (MODE == MODE_STEP || MODE == MODE_TRACE) {
+        if (is_step(MODE)) {
             if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane]);
             for (int i = 0; i < B; ++i) {
                 const int xi = __shfl(bx, i, 64), yi = __shfl(by, i, 64), di = __shfl(dig, i, 64);
@@ -592,9 +601,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
     int agg = 0, deagg = 0;
     uint32_t tick = p.tick[e];
-    if (MODE != MODE_TRACE) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    if (has_mobility(MODE)) { agg = p.agg[e]; deagg = p.deagg[e]; }
     int depth = 0, step_n = 0;
-    if (MODE == MODE_STEP || MODE == MODE_TRACE) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    if (is_step(MODE)) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
     const bool gown = lane < Gr;
 
     double sum_cur = 0.0;
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     for (int it = 0; it < n_ticks; ++it) {
         double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
         const bool aggregating = agg != 0;
-        if (MODE != MODE_TRACE) {
+        if (has_mobility(MODE)) {
             if (gown) {
                 ogx = p.g_x[e * Gr + lane]; ogy = p.g_y[e * Gr + lane]; ogfl = p.g_fl[e * Gr + lane];
                 ogv = p.g_v[e * Gr + lane]; ogc = p.g_cos[e * Gr + lane]; ogs = p.g_sin[e * Gr + lane];
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             const bool act = u < U;
             const long long iu = e * U + (act ? u : 0);
             int ix = 0, iy = 0;
-            if (MODE != MODE_TRACE) {
+            if (has_mobility(MODE)) {
                 int gid = 0;
                 for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             rx_power<BT, PLC, FAST>(p, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
             const int best = argmax_pg<BT>(p, pg);
             const double bestS = sinr_db<BT>(p, pg, best);
-            if (MODE == MODE_RESET) {
+            if (is_reset(MODE)) {
                 const unsigned long long ob = __ballot(act && (bestS <= p.out_thresh));
                 if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             }
         }  // passes
 
-        if (MODE != MODE_TRACE) {
+        if (has_mobility(MODE)) {
             if (gown) {
                 group_finish<FAST>(p, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
                 p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;

@@ -126,6 +126,10 @@ int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj
 /* MobiEnvironment.step_test in read_trace mode (mobile_env.py:196-233): UE cells come from ue_xy_in_dev [N,U,2]. */
 int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
                       const UavEnvInject *inj, const UavEnvOut *out, void *stream);
+/* MobiEnvironment.reset (and the constructor) in read_trace mode (mobile_env.py:85-89,128-131): UE cells come from
+ * ue_xy_in_dev [N,U,2] (trace row 0), no mobility tick; UAVs to their start cells, LTEChannel.reset, step_n = 0. */
+int uavenv_reset_trace(uavenv_t *h, const uint8_t *mask_dev, const int16_t *ue_xy_in_dev, const UavEnvInject *inj,
+                       const UavEnvOut *out, void *stream);
 /* env.state: (N, B+1, G, G) float32 count planes (mobile_env.py:139-140,169-170; ue_mobility.py:173-188;
  * channel.py:387-409).  Full rewrite of obs_dev. */
 int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream);

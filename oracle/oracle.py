@@ -185,6 +185,13 @@ class OracleEnv:
         lib().uavo_step(C.byref(self.cfg), C.byref(self.st), _ptr(a), self._inject(**inj), C.byref(self.out))
         return self.o
 
+    def reset_trace(self, ue_xy, mask=None, **inj):
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
+        x = np.ascontiguousarray(np.asarray(ue_xy, np.int16).reshape(self.N, self.U, 2))
+        lib().uavo_reset_trace(C.byref(self.cfg), C.byref(self.st), _ptr(m), _ptr(x), self._inject(**inj),
+                               C.byref(self.out))
+        return self.o
+
     def step_trace(self, actions, ue_xy, **inj):
         a = np.ascontiguousarray(np.asarray(actions, np.int64).reshape(self.N))
         x = np.ascontiguousarray(np.asarray(ue_xy, np.int16).reshape(self.N, self.U, 2))

@@ -398,6 +398,37 @@ int uavo_reset(const UavoConfig *cfg, UavoState *st, const uint8_t *mask, const 
     return 0;
 }
 
+/* reset() in read_trace mode, mobile_env.py:119,128-131,137,146: ueLoc = ueLoc_trace[0], no next(self.mm) */
+int uavo_reset_trace(const UavoConfig *cfg, UavoState *st, const uint8_t *mask, const int16_t *ue_xy_in,
+                     const UavoInject *inj, UavoOut *out) {
+    const int U = cfg->n_ue, B = cfg->n_bs;
+    double *fading = (double *)malloc(sizeof(double) * U * B * 2 + sizeof(double) * U);
+    double *sinr = fading + U * B, *cur = sinr + U * B;
+    for (int64_t e = 0; e < st->n_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        for (int b = 0; b < B; ++b) {
+            st->bs_xy[(e * B + b) * 2 + 0] = cfg->bs_init_xy[b][0];
+            st->bs_xy[(e * B + b) * 2 + 1] = cfg->bs_init_xy[b][1];
+        }
+        memcpy(st->ue_xy + e * 2 * U, ue_xy_in + e * 2 * U, sizeof(int16_t) * 2 * U);
+        st->tick[e] += 1; /* Philox time advances once per channel update */
+        channel_reset(cfg, st, e, inj, out, fading, sinr, cur);
+        st->step_n[e] = 0;
+        if (out) {
+            if (out->step_n) out->step_n[e] = 0;
+            if (out->reward) out->reward[e] = 0.f;
+            if (out->done) out->done[e] = 0;
+            if (out->n_out) out->n_out[e] = 0;
+            double m = uavo_np_pairwise_sum(cur, U) / (double)U;
+            if (out->mean_sinr) out->mean_sinr[e] = (float)m;
+            if (out->mean_sinr_f64) out->mean_sinr_f64[e] = m;
+            if (out->reward_f64) out->reward_f64[e] = 0.0;
+        }
+    }
+    free(fading);
+    return 0;
+}
+
 /* ---- UpdateDroneNet (DL part), channel.py:138-216, + reward, mobile_env.py:163-189 ----- */
 static void channel_update(const UavoConfig *cfg, UavoState *st, int64_t e, const UavoInject *inj,
                            UavoOut *out, double *fading, double *sinr, double *cur) {

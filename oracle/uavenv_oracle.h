@@ -94,6 +94,9 @@ int uavo_step(const UavoConfig *cfg, UavoState *st, const int64_t *actions, cons
 /* step_test with read_trace: UE ints come from the trace, no mobility tick (mobile_env.py:202-203) */
 int uavo_step_trace(const UavoConfig *cfg, UavoState *st, const int64_t *actions, const int16_t *ue_xy_in,
                     const UavoInject *inj, UavoOut *out);
+/* reset with read_trace: UE ints from the trace, no mobility tick (mobile_env.py:128-131) */
+int uavo_reset_trace(const UavoConfig *cfg, UavoState *st, const uint8_t *mask, const int16_t *ue_xy_in,
+                     const UavoInject *inj, UavoOut *out);
 int uavo_obs_dense(const UavoConfig *cfg, const UavoState *st, float *obs);
 void uavo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double uavo_np_pairwise_sum(const double *a, int64_t n);

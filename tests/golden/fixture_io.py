@@ -76,6 +76,15 @@ def regenerate_draws(fx):
     return out
 
 
+def regenerate_trace_fading(fx):
+    """read_trace fixtures: the only draws are the U*B normals of each channel update (constructor, then one
+    per reset / step_test), consumed from RandomState(seed) in order."""
+    rs = np.random.RandomState(int(fx["seed"]))
+    E = len(fx["ev_kind"])
+    U, B = int(fx["n_ue"]), int(fx["n_bs"])
+    return np.stack([rs.normal(0.0, 2.0, size=(U, B)) for _ in range(E + 1)])
+
+
 def load_fixture(path):
     with np.load(path, allow_pickle=False) as z:
         fx = {k: z[k] for k in z.files}

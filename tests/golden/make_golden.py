@@ -283,6 +283,83 @@ def run_parts_scenario(name, seed, n_bs, groups, grid, bs_init, actions):
     finish_fixture(name, meta, rec, probe, ev, extra)
 
 
+def run_trace_scenario(name, seed, n_steps, trace_len):
+    """BASELINE config 1: MobiEnvironment(4, 40, 100, "read_trace", file) driven by step_test
+    (main_test.py:51-75).  ue_trace_10k.npy is absent from the mount (.MISSING_LARGE_BLOBS), so a trace of the
+    same format (T, 40, 2) int is produced the way README.md:32 / main_test.py:114 describe: the group model's
+    integer positions."""
+    import tempfile
+
+    mods = load_reference()
+    me, um = mods["mobile_env"], mods["ue_mobility"]
+    B, U, G = 4, 40, 100
+    np.random.seed(seed + 1000)
+    mm = um.reference_point_group([10, 10, 10, 10], dimensions=(G, G), velocity=(0, 1), aggregation=0.8)
+    for _ in range(200):
+        next(mm)
+    trace = np.stack([next(mm).astype(int) for _ in range(trace_len)]).astype(np.int16)
+    rs = np.random.RandomState(777)
+    actions = rs.randint(0, 625, n_steps)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "trace.npy")
+        np.save(path, trace)
+        np.random.seed(seed)
+        with Recorder(mods) as rec:
+            env = me.MobiEnvironment(B, U, G, "read_trace", path)
+            c0 = channel_snapshot(env.channel, U)
+            script = [("reset",)] + [("step", int(a)) for a in actions[:n_steps // 2]] + [("reset",)] + \
+                     [("step", int(a)) for a in actions[n_steps // 2:]]
+            E = len(script)
+            ev = {
+                "ev_kind": np.zeros(E, np.int8), "ev_action": np.zeros(E, np.int64),
+                "ev_trace_row": np.zeros(E, np.int32),
+                "ue_loc": np.zeros((E, U, 2), np.int16), "bs_loc": np.zeros((E, B, 2), np.int16),
+                "serving": np.zeros((E, U), np.int8), "cur_sinr": np.zeros((E, U)),
+                "fifo": np.zeros((E, 3, U), np.int8), "fifo_depth": np.zeros(E, np.int8),
+                "out_mask": np.zeros((E, U), bool), "mean_sinr": np.full(E, np.nan),
+                "n_out": np.zeros(E, np.int32), "reward": np.full(E, np.nan),
+                "done": np.zeros(E, bool), "step_n": np.zeros(E, np.int32),
+                "state_nz": np.zeros((E, U + B, 4), np.int16), "bs_actions": np.zeros((E, B), np.int8),
+                "outage_fraction": np.zeros(E),
+            }
+            for e, item in enumerate(script):
+                if item[0] == "reset":
+                    state = env.reset()
+                    ev["ev_kind"][e] = 0
+                    ev["ev_trace_row"][e] = 0
+                else:
+                    ev["ev_trace_row"][e] = env.step_n          # mobile_env.py:203 ueLoc_trace[self.step_n]
+                    state, reward, done, info = env.step_test(item[1])
+                    ev["ev_kind"][e] = 1
+                    ev["ev_action"][e] = item[1]
+                    ev["reward"][e] = reward
+                    ev["done"][e] = done
+                    ev["mean_sinr"][e] = float(np.mean(env.channel.current_BS_sinr))
+                    ev["n_out"][e] = int(round(info.outage_fraction * U))
+                    ev["outage_fraction"][e] = info.outage_fraction
+                    ev["bs_actions"][e] = info.bs_actions
+                serv, sinr, fifo, depth, omask = channel_snapshot(env.channel, U)
+                ev["ue_loc"][e] = np.asarray(env.ueLoc)[:, :2]
+                ev["bs_loc"][e] = env.bsLoc[:, :2]
+                ev["serving"][e], ev["cur_sinr"][e] = serv, sinr
+                ev["fifo"][e], ev["fifo_depth"][e], ev["out_mask"][e] = fifo, depth, omask
+                ev["step_n"][e] = env.step_n
+                ev["state_nz"][e] = state_nonzeros(state, U + B)
+    assert len(rec.rand_log) == 0, "read_trace mode must not draw uniforms"
+    normals = np.array(rec.normal_log)
+    assert normals.size == (E + 1) * U * B
+    fx = {"seed": seed, "n_walkers": U, "n_ue_channel_rows": U, "n_bs": B, "n_ue": U, "n_groups": 4,
+          "groups": np.array([10, 10, 10, 10], np.int32), "grid": G, "warmup_ticks": 0, "max_step": int(me.MAXSTEP),
+          "bs_init": np.array(env.initBsLoc[:, :2], np.int16), "trace": trace,
+          "init_ue_loc": trace[0], "init_serving": c0[0], "init_cur_sinr": c0[1], "init_out_mask": c0[4]}
+    fx.update(ev)
+    from fixture_io import regenerate_trace_fading
+    assert np.array_equal(regenerate_trace_fading(fx), normals.reshape(E + 1, U, B))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in fx.items()})
+    print("%-34s E=%d trace rows=%d handovers=n/a  %.1f KB" % (name, E, trace_len, os.path.getsize(path) / 1024.0))
+
+
 def probe_last_ue(probe, W):
     s = probe.snaps[W - 1]
     return np.stack([s["x"], s["y"]], axis=1).astype(int)
@@ -340,7 +417,10 @@ def scenario_list():
         script += [("step", a) for a in rng.randint(0, 625, 30)]
         run_env_scenario("ref_4x40_g100_seed5_walls", 5, 40, 100, [10, 10, 10, 10], script)
 
-    sc["s1"], sc["s2"], sc["s3"], sc["s4"], sc["s5"] = s1, s2, s3, s4, s5
+    def s6():
+        run_trace_scenario("ref_trace_4x40_g100_seed6", 6, 240, 260)
+
+    sc["s1"], sc["s2"], sc["s3"], sc["s4"], sc["s5"], sc["s6"] = s1, s2, s3, s4, s5, s6
     return sc
 
 

@@ -31,3 +31,13 @@ class HipEnvAdapter:
     @property
     def s(self):
         return self.env.state_fields()
+
+    def reset_trace(self, ue_xy, mask=None, fading=None):
+        self.env.reset_trace(ue_xy, mask=mask, fading=fading)
+        return self._np()
+
+    def step_trace(self, actions, ue_xy, fading=None):
+        import torch
+
+        self.env.step_trace(torch.as_tensor(np.asarray(actions, np.int64)), ue_xy, fading=fading)
+        return self._np()

@@ -82,3 +82,29 @@ def make_checker(fx, n_envs, f64_tol=1e-9, f32_rtol=1e-5, has_f64=True, stats=No
             stats["events"] = stats.get("events", 0) + 1
 
     return check
+
+
+def replay_trace_fixture(env, fx, n_envs=1, check=None):
+    """read_trace fixtures (BASELINE config 1): constructor = reset_trace(trace[0]); 'reset' events the same;
+    'step' events = step_test with UE cells trace[row] (mobile_env.py:85-89,128-131,202-203)."""
+    from fixture_io import regenerate_trace_fading
+
+    N = n_envs
+    fading = regenerate_trace_fading(fx)
+    trace = fx["trace"]
+    env.init()  # mobility state is unused in read_trace mode but must be defined
+    out = env.reset_trace(tile(trace[0], N), fading=tile(fading[0], N))
+    if check:
+        check(-1, "ctor", out, env)
+    for e in range(len(fx["ev_kind"])):
+        f = tile(fading[e + 1], N)
+        if fx["ev_kind"][e] == 0:
+            out = env.reset_trace(tile(trace[0], N), fading=f)
+            kind = "reset"
+        else:
+            row = int(fx["ev_trace_row"][e])
+            out = env.step_trace(np.full(N, int(fx["ev_action"][e]), np.int64), tile(trace[row], N), fading=f)
+            kind = "step"
+        if check:
+            check(e, kind, out, env)
+    return env

@@ -81,6 +81,40 @@ def test_hip_replays_reference(golden):
     assert stats["events"] == len(fx["ev_kind"]) + 1
 
 
+def test_hip_replays_reference_read_trace():
+    """BASELINE config 1 on the HIP path: reset_trace / step_trace against the reference's step_test run."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from fixture_io import load_fixture
+    from hip_adapter import HipEnvAdapter
+    from replay import make_checker, replay_trace_fixture
+
+    fx = load_fixture(os.path.join(GOLDEN_DIR, "ref_trace_4x40_g100_seed6.npz"))
+    fx["name"] = "ref_trace_4x40_g100_seed6"
+    N = 2
+    env = _make(N, fx, f64_outputs=True, construct=False)
+    ad = HipEnvAdapter(env)
+    U = fx["n_ue"]
+    base = make_checker(fx, N, f64_tol=1e-9, f32_rtol=F32_RTOL)
+    seen = {"n": 0}
+
+    def check(e, kind, out, ad):
+        base(e, kind, out, ad)
+        seen["n"] += 1
+        if kind == "ctor" or e % 8:
+            return
+        s = ad.s
+        for n in range(N):
+            depth = int(fx["fifo_depth"][e])
+            assert int(s["fifo_depth"][n]) == depth
+            np.testing.assert_array_equal(s["fifo"][n][:depth], fx["fifo"][e][:depth])
+            np.testing.assert_array_equal(_bits(s["out_bits"][n], U), fx["out_mask"][e])
+
+    replay_trace_fixture(ad, fx, N, check)
+    assert seen["n"] == len(fx["ev_kind"]) + 1
+
+
 def _bits(words, U):
     return np.array([(int(words[u // 64]) >> (u % 64)) & 1 for u in range(U)], bool)
 

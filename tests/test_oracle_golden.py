@@ -62,3 +62,39 @@ def test_np_pairwise_sum_matches_numpy():
         for _ in range(50):
             a = rs.randn(n) * 10.0 ** rs.uniform(-3, 3, n)
             assert O.np_pairwise_sum(a) == float(np.sum(a))
+
+
+def test_oracle_replays_reference_read_trace():
+    """BASELINE config 1: MobiEnvironment(4, 40, 100, 'read_trace', ...) + step_test, captured from the reference."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from fixture_io import load_fixture
+    from replay import replay_trace_fixture
+
+    fx = load_fixture(os.path.join(GOLDEN_DIR, "ref_trace_4x40_g100_seed6.npz"))
+    fx["name"] = "ref_trace_4x40_g100_seed6"
+    env = O.OracleEnv(_cfg(fx), 1)
+    U = fx["n_ue"]
+    base = make_checker(fx, 1, f64_tol=1e-9)
+    seen = {"n": 0}
+
+    def check(e, kind, out, env):
+        base(e, kind, out, env)
+        seen["n"] += 1
+        if kind == "ctor":
+            np.testing.assert_array_equal(_bits(env.s["out_bits"][0], U), fx["init_out_mask"])
+            return
+        depth = int(fx["fifo_depth"][e])
+        assert int(env.s["fifo_depth"][0]) == depth
+        np.testing.assert_array_equal(env.s["fifo"][0][:depth], fx["fifo"][e][:depth])
+        np.testing.assert_array_equal(_bits(env.s["out_bits"][0], U), fx["out_mask"][e])
+        if e % 16 == 0:
+            obs = env.obs_dense()[0]
+            nz = np.argwhere(obs != 0)
+            got = sorted((int(p), int(x), int(y), int(obs[p, x, y])) for p, x, y in nz)
+            want = sorted(tuple(int(v) for v in r) for r in fx["state_nz"][e] if r[0] >= 0)
+            assert got == want
+
+    replay_trace_fixture(env, fx, 1, check)
+    assert seen["n"] == len(fx["ev_kind"]) + 1
