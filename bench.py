@@ -96,10 +96,12 @@ def main():
     torch.cuda.set_device(dev)
 
     from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.sharding import max_over_ranks, shard_for_rank, whole_job_rate
 
     E, K, W = args.envs, args.steps, args.warmup
+    env_id_base, _ = shard_for_rank(rank, world, E)   # rank r owns global envs [r*E, (r+1)*E): no env-path collective
     env = BatchedMobiEnv(E, nBS=N_BS, nUE=N_UE, grid_n=GRID, groups=GROUPS, device=dev, seed=SEED,
-                         env_id_base=rank * E)
+                         env_id_base=env_id_base)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_act = min(K + W, 512)  # action table resident in HBM, cycled
     actions = torch.randint(0, env.action_space_dim, (n_act, E), generator=gen, dtype=torch.int64).to(dev)
@@ -125,18 +127,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([elapsed, gpu_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms = float(t[0]), float(t[1])
+    elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=dev)   # slowest rank (identity at N=1)
 
     if rank == 0:
-        total_env_steps = world * E * K
         per_launch_s = gpu_ms * 1e-3 / K  # average launch-to-launch time of the step kernel (HIP events)
         b_step = algorithmic_bytes_per_env_step(N_UE, N_BS, len(GROUPS))
         achieved = b_step * E / per_launch_s / 1e9
         line = {
-            "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": total_env_steps / elapsed,
+            "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
             "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
