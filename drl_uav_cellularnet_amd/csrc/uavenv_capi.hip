@@ -200,8 +200,9 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.k_pl = k.p_bs_watt * std::pow(10.0, (cfg->antenna_gain - cfg->pl_a - cfg->eq_loss) / 10.0);
     k.k_0 = k.p_bs_watt * std::pow(10.0, (cfg->antenna_gain - cfg->eq_loss) / 10.0);
     k.c_exp = -std::log2(10.0) / 10.0;      // 10^(-f/10) = 2^(c_exp*f)
-    k.pl_exp = cfg->pl_b / 10.0;            // d^(-pl_b/10) = 2^(-pl_exp*log2(d))
-    k.db_per_log2 = 10.0 / std::log2(10.0); // 10*log10(x) = db_per_log2*log2(x)
+    k.pl_exp_ln = (cfg->pl_b / 10.0) * 0.5 / std::log(2.0);  // d^(-pl_b/10) = 2^(-pl_exp_ln * ln(d^2))
+    k.pl_dis2 = cfg->pl_dis < 0.0 ? -1.0 : cfg->pl_dis * cfg->pl_dis;  // d > pl_dis  <=>  d^2 > pl_dis2 (d >= 0)
+    k.db_per_ln = 10.0 / std::log(10.0);     // 10*log10(x) = db_per_ln * ln(x)
     h->plc = (cfg->pl_b == 30.0);
     k.pl_a = cfg->pl_a; k.pl_b = cfg->pl_b; k.pl_dis = cfg->pl_dis; k.antenna_gain = cfg->antenna_gain;
     k.eq_loss = cfg->eq_loss; k.shadow_mean = cfg->shadow_mean; k.shadow_sd = cfg->shadow_sd;

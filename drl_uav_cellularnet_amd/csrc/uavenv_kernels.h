@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lean_math.h"
 #include "philox.h"
 
 namespace uavk {
@@ -62,7 +63,7 @@ struct KParams {
     int group_start[kMaxGroups + 1];
     int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
     double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
-    double k_pl, k_0, c_exp, pl_exp, db_per_log2;  // folded constants, see rx_power()
+    double k_pl, k_0, c_exp, pl_exp_ln, pl_dis2, db_per_ln;  // folded constants, see rx_power() / sinr_db()
     double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
     long long N;
     uint32_t key0, key1, env_id_base;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, 
     // group centre; arctan2(0, 0) = 0 gives (1, 0).
     const double dxc = gx - x, dyc = gy - y;
     const double r2 = dxc * dxc + dyc * dyc;
-    const double rinv = 1.0 / sqrt(r2);
+    const double rinv = lm_rsqrt(r2);         // r2 == 0 gives inf; the selects below discard it
     const double cc = (r2 > 0.0) ? dxc * rinv : 1.0;
     const double sc = (r2 > 0.0) ? dyc * rinv : 0.0;
     x = x + gv * gc;                          // :469 / :483
@@ -199,7 +200,7 @@ __device__ __forceinline__ void group_finish(const KParams &p, long long e, int 
 // Received power P*gain of every UAV at one walker (channel.py:220-257), linear domain.
 // The reference goes through dB and back (loss = a + b*log10(d); gain = 10^((ant-loss-f-eq)/10)).
 // Same value with fewer transcendentals:
-//     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3, no log at all: PLC)
+//     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3 = rsqrt(d^2)^3, no log: PLC)
 //            = k_0  * 10^(-f/10)               otherwise (loss = 0)
 // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
 // bs: this env's UAV cells in LDS ([2*B] ints).  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
@@ -220,7 +221,8 @@ __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t
             } else {
                 double u0, u1;
                 philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
-                const double r = sqrt(-2.0 * log(1.0 - u0));
+                const double t = -2.0 * lm_log(1.0 - u0);          // 1-u0 in [2^-53, 1]: positive, normal
+                const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;   // sqrt(t); t == 0 only when u0 == 0
                 double sa, ca;
                 sincospi(2.0 * u1, &sa, &ca);
                 f0 = p.shadow_mean + p.shadow_sd * (r * ca);
@@ -236,10 +238,14 @@ __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t
                     const double f = (k == 0) ? f0 : f1;
                     const double fx = p.grid_width * (double)(ix - bs[2 * b]);       // :221-222
                     const double fy = p.grid_width * (double)(iy - bs[2 * b + 1]);
-                    const double d = sqrt(fx * fx + fy * fy);                         // :223 (z ignored)
-                    if (PLC) g = p.k_pl * exp2(p.c_exp * f) / (d * d * d);
-                    else g = p.k_pl * exp2(p.c_exp * f - p.pl_exp * log2(d));
-                    if (!(d > p.pl_dis)) g = p.k_0 * exp2(p.c_exp * f);               // :232-233
+                    const double d2 = fx * fx + fy * fy;                              // d^2, :223 (z ignored); exact
+                    if (PLC) {
+                        const double rinv = lm_rsqrt(d2);                             // d^-3 = (d2^-1/2)^3
+                        g = p.k_pl * exp2(p.c_exp * f) * (rinv * rinv * rinv);
+                    } else {
+                        g = p.k_pl * exp2(p.c_exp * f - p.pl_exp_ln * lm_log(d2));    // d^(-b/10) = e^(-(b/20) ln d2)
+                    }
+                    if (!(d2 > p.pl_dis2)) g = p.k_0 * exp2(p.c_exp * f);             // d <= pl_dis: loss = 0 (:232-233)
                 }
                 pg[b] = g;
             }
@@ -269,7 +275,7 @@ __device__ __forceinline__ double sinr_db(const KParams &p, const double pg[BT],
         interf += (j != x && j < p.B) ? pg[j] : 0.0;
         px = (j == x) ? pg[j] : px;
     }
-    return p.db_per_log2 * log2(px / (p.noise_watt + interf));
+    return p.db_per_ln * lm_log(px / (p.noise_watt + interf));   // 10*log10(x) = (10/ln 10) * ln x
 }
 
 // bestBS_buf push + handover decision for one UE (channel.py:148-167).  r0..r2 = FIFO rows, oldest first.

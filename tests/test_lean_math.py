@@ -1,0 +1,25 @@
+"""CPU: accuracy of the lean float64 log used by the kernels (csrc/lean_math.h), measured on the host against a
+long double reference over 2e6 samples per argument domain.  The header is host+device, so this is the same
+source the kernel compiles (the device build contracts a*b+c into FMAs, which can only tighten the error).
+The rsqrt row exercises the host stand-in only (the device calls ocml rsqrt); it is reported, not asserted --
+the device function is judged by the GPU parity tests (float64 outputs within 1e-9 of the oracle)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lm_log_is_below_one_ulp(tmp_path):
+    exe = os.path.join(tmp_path, "lean_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "lean_math_check.cpp")])
+    rows = {}
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        name, n, worst, mean = line.split()
+        rows[name] = (int(n), float(worst), float(mean))
+    for name in ("log_one_minus_u", "log_sinr_ratio", "log_near_one"):
+        n, worst, mean = rows[name]
+        assert n == 2000000
+        assert worst < 1.0, "%s: max error %.3f ulp" % (name, worst)      # fdlibm's bound for this algorithm
+        assert mean < 0.3
+    assert "rsqrt_dist2" in rows
