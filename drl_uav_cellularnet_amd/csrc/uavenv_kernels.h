@@ -94,6 +94,21 @@ struct InitParams {
 // shared device helpers (both env kernels run exactly this arithmetic)
 // ================================================================================================
 
+// Hot-path float64 constants, copied once from the kernarg block into PINNED VGPRs.  Left in SGPRs they (15 doubles
+// = 30 SGPRs) compete with ~30 pointers and the per-lane booleans for the 102-SGPR file, and the overflow is
+// spilled through v_writelane/v_readlane, i.e. paid in VALU issue slots; VGPRs are plentiful here.
+struct HotConst {
+    double vel, aggr, maxc, sh_mean, sh_sd, c_exp, k_pl, k_0, pl_dis2, pl_exp_ln, noise, db_per_ln, ho_thr, out_thr, gw;
+};
+__device__ __forceinline__ HotConst make_hot(const KParams &p) {
+    HotConst h = {p.ue_velocity, p.aggregation, (double)p.G, p.shadow_mean, p.shadow_sd, p.c_exp, p.k_pl, p.k_0,
+                  p.pl_dis2, p.pl_exp_ln, p.noise_watt, p.db_per_ln, p.ho_thresh_db, p.out_thresh, p.grid_width};
+    lm_pin(h.vel); lm_pin(h.aggr); lm_pin(h.maxc); lm_pin(h.sh_mean); lm_pin(h.sh_sd); lm_pin(h.c_exp); lm_pin(h.k_pl);
+    lm_pin(h.k_0); lm_pin(h.pl_dis2); lm_pin(h.pl_exp_ln); lm_pin(h.noise); lm_pin(h.db_per_ln); lm_pin(h.ho_thr);
+    lm_pin(h.out_thr); lm_pin(h.gw);
+    return h;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -142,13 +157,13 @@ __device__ __forceinline__ void uav_propose(const KParams &p, int xi, int yi, in
 // One next() of reference_point_group for one walker (ue_mobility.py:455-505): own step along the heading
 // drawn last tick, group step (+ pull towards the group centre while aggregating), then the four ordered
 // bounce tests.  c[k] report which tests fired (they flip the GROUP heading, once per group and test).
-__device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, double hu, double gx, double gy,
-                                            double gv, double gc, double gs, double MAXC, double &x, double &y,
+__device__ __forceinline__ void walker_move(const HotConst &H, const LeanCoef &C, bool aggregating, double hu, double gx,
+                                            double gy, double gv, double gc, double gs, double MAXC, double &x, double &y,
                                             bool c[4]) {
     double sn, cs;
-    sincospi(2.0 * hu, &sn, &cs);             // theta = 2*pi*u  (:437,508)
-    x = x + p.ue_velocity * cs;               // :455
-    y = y + p.ue_velocity * sn;               // :456
+    lm_sincospi(2.0 * hu, C, &sn, &cs);       // theta = 2*pi*u  (:437,508)
+    x = x + H.vel * cs;                       // :455
+    y = y + H.vel * sn;                       // :456
     // cos/sin of c_theta = arctan2(g_y - y, g_x - x) (:467) are the normalised components of the vector to the
     // group centre; arctan2(0, 0) = 0 gives (1, 0).
     const double dxc = gx - x, dyc = gy - y;
@@ -159,8 +174,8 @@ __device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, 
     x = x + gv * gc;                          // :469 / :483
     y = y + gv * gs;                          // :470 / :484
     if (aggregating) {                        // :461-470 (per-lane select: slots may be in different phases)
-        x = x + p.aggregation * cc;
-        y = y + p.aggregation * sc;
+        x = x + H.aggr * cc;
+        y = y + H.aggr * sc;
     }
     c[0] = x < 0.0;                           // :490-493
     if (c[0]) x = -x;
@@ -174,7 +189,7 @@ __device__ __forceinline__ void walker_move(const KParams &p, bool aggregating, 
 
 // Group owner, end of tick (ue_mobility.py:493-521): bounce flips, remaining flight length, arrival redraw.
 template <bool FAST>
-__device__ __forceinline__ void group_finish(const KParams &p, long long e, int g, uint32_t tick, const uint32_t touched[4],
+__device__ __forceinline__ void group_finish(const KParams &p, const LeanCoef &C, long long e, int g, uint32_t tick, const uint32_t touched[4],
                                              double MAXC, double &ogfl, double &ogv, double &ogc, double &ogs) {
     const uint32_t bit = 1u << g;
     if (touched[0] & bit) ogc = -ogc;
@@ -191,7 +206,7 @@ __device__ __forceinline__ void group_finish(const KParams &p, long long e, int 
             philox_u2(p, (uint32_t)e, tick, (uint32_t)g, DOM_GROUP_A, ut, uf);
             philox_u2(p, (uint32_t)e, tick, (uint32_t)g, DOM_GROUP_B, uv, t1);
         }
-        sincospi(2.0 * ut, &ogs, &ogc);                   // :517-519
+        lm_sincospi(2.0 * ut, C, &ogs, &ogc);             // :517-519
         ogfl = uf * MAXC;                                 // :520 FL_MAX = max(dimensions)
         ogv = uv * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :521
     }
@@ -206,8 +221,8 @@ __device__ __forceinline__ void group_finish(const KParams &p, long long e, int 
 // bs: this env's UAV cells in LDS ([2*B] ints).  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
 // Philox uniforms (one call -> two UAVs), replacing np.random.normal (channel.py:240).
 template <int BT, bool PLC, bool FAST>
-__device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t tick, int u, bool act, long long iu,
-                                         int ix, int iy, const int *bs, double pg[BT]) {
+__device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, const LeanCoef &C, long long e, uint32_t tick, int u, bool act,
+                                         long long iu, int ix, int iy, const int *bs, double pg[BT]) {
     const int B = p.B;
 #pragma unroll
     for (int b2 = 0; b2 < BT; b2 += 2) {
@@ -221,12 +236,12 @@ __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t
             } else {
                 double u0, u1;
                 philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
-                const double t = -2.0 * lm_log(1.0 - u0);          // 1-u0 in [2^-53, 1]: positive, normal
+                const double t = -2.0 * lm_logc(1.0 - u0, C);      // 1-u0 in [2^-53, 1]: positive, normal
                 const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;   // sqrt(t); t == 0 only when u0 == 0
                 double sa, ca;
-                sincospi(2.0 * u1, &sa, &ca);
-                f0 = p.shadow_mean + p.shadow_sd * (r * ca);
-                f1 = p.shadow_mean + p.shadow_sd * (r * sa);
+                lm_sincospi(2.0 * u1, C, &sa, &ca);
+                f0 = H.sh_mean + H.sh_sd * (r * ca);
+                f1 = H.sh_mean + H.sh_sd * (r * sa);
             }
         }
 #pragma unroll
@@ -236,16 +251,16 @@ __device__ __forceinline__ void rx_power(const KParams &p, long long e, uint32_t
                 double g = 0.0;
                 if (b < B) {
                     const double f = (k == 0) ? f0 : f1;
-                    const double fx = p.grid_width * (double)(ix - bs[2 * b]);       // :221-222
-                    const double fy = p.grid_width * (double)(iy - bs[2 * b + 1]);
+                    const double fx = H.gw * (double)(ix - bs[2 * b]);                // :221-222
+                    const double fy = H.gw * (double)(iy - bs[2 * b + 1]);
                     const double d2 = fx * fx + fy * fy;                              // d^2, :223 (z ignored); exact
                     if (PLC) {
                         const double rinv = lm_rsqrt(d2);                             // d^-3 = (d2^-1/2)^3
-                        g = p.k_pl * exp2(p.c_exp * f) * (rinv * rinv * rinv);
+                        g = H.k_pl * lm_exp2(H.c_exp * f, C) * (rinv * rinv * rinv);
                     } else {
-                        g = p.k_pl * exp2(p.c_exp * f - p.pl_exp_ln * lm_log(d2));    // d^(-b/10) = e^(-(b/20) ln d2)
+                        g = H.k_pl * lm_exp2(H.c_exp * f - H.pl_exp_ln * lm_logc(d2, C), C);  // d^(-b/10) = 2^(-(b/20) log2 d2)
                     }
-                    if (!(d2 > p.pl_dis2)) g = p.k_0 * exp2(p.c_exp * f);             // d <= pl_dis: loss = 0 (:232-233)
+                    if (!(d2 > H.pl_dis2)) g = H.k_0 * lm_exp2(H.c_exp * f, C);       // d <= pl_dis: loss = 0 (:232-233)
                 }
                 pg[b] = g;
             }
@@ -268,25 +283,25 @@ __device__ __forceinline__ int argmax_pg(const KParams &p, const double pg[BT]) 
 // 10*log10(S/(N+I)) for UAV x (channel.py:259-268); interference = the OTHER UAVs summed in index order,
 // never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
 template <int BT>
-__device__ __forceinline__ double sinr_db(const KParams &p, const double pg[BT], int x) {
+__device__ __forceinline__ double sinr_db(const KParams &p, const HotConst &H, const LeanCoef &C, const double pg[BT], int x) {
     double interf = 0.0, px = 0.0;
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
         interf += (j != x && j < p.B) ? pg[j] : 0.0;
         px = (j == x) ? pg[j] : px;
     }
-    return p.db_per_ln * lm_log(px / (p.noise_watt + interf));   // 10*log10(x) = (10/ln 10) * ln x
+    return H.db_per_ln * lm_logc(px / (H.noise + interf), C);   // 10*log10(x) = (10/ln 10) * ln x
 }
 
 // bestBS_buf push + handover decision for one UE (channel.py:148-167).  r0..r2 = FIFO rows, oldest first.
-__device__ __forceinline__ void fifo_handover(const KParams &p, int depth, int best, double bestS, double cur,
+__device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int best, double bestS, double cur,
                                               int &serving, int &r0, int &r1, int &r2) {
     bool remain;
     if (depth == 1) { r1 = best; remain = (r1 == r0); }                       // append (:148-149)
     else if (depth == 2) { r2 = best; remain = (r1 == r0) && (r2 == r0); }
     else { r0 = r1; r1 = r2; r2 = best; remain = (r1 == r0) && (r2 == r0); }  // FIFO shift (:150-153)
     const bool changed = serving != best;                                     // :156 (newest row == best)
-    if (remain && changed && (bestS - cur > p.ho_thresh_db)) serving = best;  // :155-167
+    if (remain && changed && (bestS - cur > H.ho_thr)) serving = best;        // :155-167
 }
 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
@@ -403,9 +418,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     bool live = (lane < EPW * U) && (e < p.N);
     if (is_reset(MODE)) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
     if (__ballot(live) == 0ull) return;
+    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
+    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
     const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
-    const double MAXC = (double)p.G;
+    const double MAXC = H.maxc;
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
             const double gx = __shfl(ogx, src, 64), gy = __shfl(ogy, src, 64);
             const double gv = __shfl(ogv, src, 64), gc = __shfl(ogc, src, 64), gs = __shfl(ogs, src, 64);
             bool c[4];
-            walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);   // ue_mobility.py:455-505
+            walker_move(H, C, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);   // ue_mobility.py:455-505
             c[0] = c[0] && live; c[1] = c[1] && live; c[2] = c[2] && live; c[3] = c[3] && live;
             uint32_t touched[4] = {0u, 0u, 0u, 0u};  // per slot: groups bounced at x<0, x>MAX, y<0, y>MAX
             if (__ballot(c[0] || c[1] || c[2] || c[3]) != 0ull) {  // rare, wave-uniform branch
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
             }
             if (UAV_INJ(p.inj_theta)) hu = hu_inj;                                       // new heading (:508)
             else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
-            if (gown) group_finish<FAST>(p, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);   // :493-521
+            if (gown) group_finish<FAST>(p, C, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);   // :493-521
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }            // :472-473
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }                        // :486-487
         }
@@ -513,9 +530,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     unsigned long long ob = 0ull;
     if (MODE != MODE_WARMUP) {
         double pg[BT];
-        rx_power<BT, PLC, FAST>(p, e, tick - 1u, u, live, iu, ix, iy, bs_row, pg);
+        rx_power<BT, PLC, FAST>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bs_row, pg);
         const int best = argmax_pg<BT>(p, pg);
-        const double bestS = sinr_db<BT>(p, pg, best);
+        const double bestS = sinr_db<BT>(p, H, C, pg, best);
         if (is_reset(MODE)) {
             // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
             cur = bestS;
@@ -523,10 +540,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
             r0 = best;                                                                   // bestBS_buf = [current_BS]
         } else {
             // UpdateDroneNet, DL part (channel.py:141-174)
-            cur = sinr_db<BT>(p, pg, serving);       // serving UAV BEFORE any handover (:145-146)
-            fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
+            cur = sinr_db<BT>(p, H, C, pg, serving);       // serving UAV BEFORE any handover (:145-146)
+            fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
         }
-        ob = (__ballot(live && (cur <= p.out_thresh)) & slot_mask) >> base;               // :116 / :170
+        ob = (__ballot(live && (cur <= H.out_thr)) & slot_mask) >> base;               // :116 / :170
         if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
         sum_cur = slot_sum(live ? cur : 0.0, ul, U);
     }
@@ -572,9 +589,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
     if (e >= p.N) return;
     if (is_reset(MODE)) { if (p.mask != nullptr && p.mask[e] == 0) return; }
+    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
+    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
 
     const int U = p.U, B = p.B, Gr = p.Gr;
-    const double MAXC = (double)p.G;
+    const double MAXC = H.maxc;
     const int n_pass = (U + 63) >> 6;
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
 
@@ -641,7 +660,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                 double x = 0, y = 0, hu = 0;
                 if (act) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
                 bool c[4];
-                walker_move(p, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
+                walker_move(H, C, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
                 c[0] = c[0] && act; c[1] = c[1] && act; c[2] = c[2] && act; c[3] = c[3] && act;
                 if (__ballot(c[0] || c[1] || c[2] || c[3]) != 0ull) {
                     for (int g = 0; g < Gr; ++g) {
@@ -666,11 +685,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
             double pg[BT];
-            rx_power<BT, PLC, FAST>(p, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
+            rx_power<BT, PLC, FAST>(p, H, C, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
             const int best = argmax_pg<BT>(p, pg);
-            const double bestS = sinr_db<BT>(p, pg, best);
+            const double bestS = sinr_db<BT>(p, H, C, pg, best);
             if (is_reset(MODE)) {
-                const unsigned long long ob = __ballot(act && (bestS <= p.out_thresh));
+                const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
                 if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
                     p.serving[iu] = (int8_t)best;
@@ -686,9 +705,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                     serving = p.serving[iu];
                     r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
                 }
-                const double cur = sinr_db<BT>(p, pg, serving);
-                fifo_handover(p, depth, best, bestS, cur, serving, r0, r1, r2);
-                const unsigned long long ob = __ballot(act && (cur <= p.out_thresh));
+                const double cur = sinr_db<BT>(p, H, C, pg, serving);
+                fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
+                const unsigned long long ob = __ballot(act && (cur <= H.out_thr));
                 const unsigned long long prev = p.out_bits[e * p.W64 + pass];
                 n_outage += __popcll(ob & ~prev);
                 if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
@@ -707,7 +726,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
         if (has_mobility(MODE)) {
             if (gown) {
-                group_finish<FAST>(p, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
+                group_finish<FAST>(p, C, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
                 p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;
                 p.g_v[e * Gr + lane] = ogv; p.g_cos[e * Gr + lane] = ogc; p.g_sin[e * Gr + lane] = ogs;
             }

@@ -41,6 +41,26 @@ int main() {
     // near 1 (SINR near 0 dB: the region the 1e-5 relative bound of the float32 output is sensitive to)
     run("log_near_one", [](double x) { return uavk::lm_log(x); }, [](long double x) { return std::log(x); },
         [&](std::mt19937_64 &g) { return 1.0 + (u01(g) - 0.5) * 1e-3; }, n);
+    const uavk::LeanCoef C = uavk::lm_make_coef();
+    run("logc_sinr_ratio", [&](double x) { return uavk::lm_logc(x, C); }, [](long double x) { return std::log(x); },
+        [&](std::mt19937_64 &g) { return std::pow(10.0, -20.0 + 33.0 * u01(g)); }, n);
+    // 10^(-f/10) = 2^(c*f), f ~ N(0,2) -> |x| < ~4; generic path-loss exponent adds down to ~ -40
+    run("exp2_fading", [&](double x) { return uavk::lm_exp2(x, C); }, [](long double x) { return std::exp2(x); },
+        [&](std::mt19937_64 &g) { return -4.0 + 8.0 * u01(g); }, n);
+    run("exp2_wide", [&](double x) { return uavk::lm_exp2(x, C); }, [](long double x) { return std::exp2(x); },
+        [&](std::mt19937_64 &g) { return -60.0 + 70.0 * u01(g); }, n);
+    // sincospi on [0,2): reference with the SAME exact reduction (pi*x in long double would lose the zeros of sin)
+    auto red = [](long double x, int &iq) { long double q = std::rint(2.0L * x); iq = (int)q; return x - 0.5L * q; };
+    run("sinpi_0_2", [&](double x) { double s, c; uavk::lm_sincospi(x, C, &s, &c); return s; },
+        [&](long double x) { int iq; long double r = red(x, iq); long double sr = std::sin(3.14159265358979323846264338327950288L * r),
+                             cr = std::cos(3.14159265358979323846264338327950288L * r);
+                             switch (iq & 3) { case 0: return sr; case 1: return cr; case 2: return -sr; default: return -cr; } },
+        [&](std::mt19937_64 &g) { return 2.0 * u01(g); }, n);
+    run("cospi_0_2", [&](double x) { double s, c; uavk::lm_sincospi(x, C, &s, &c); return c; },
+        [&](long double x) { int iq; long double r = red(x, iq); long double sr = std::sin(3.14159265358979323846264338327950288L * r),
+                             cr = std::cos(3.14159265358979323846264338327950288L * r);
+                             switch (iq & 3) { case 0: return cr; case 1: return -sr; case 2: return -cr; default: return sr; } },
+        [&](std::mt19937_64 &g) { return 2.0 * u01(g); }, n);
     run("rsqrt_dist2", [](double x) { return uavk::lm_rsqrt(x); }, [](long double x) { return 1.0L / std::sqrt(x); },
         [&](std::mt19937_64 &g) { return 25.0 * (double)(1 + g() % 2000000); }, n);
     return 0;

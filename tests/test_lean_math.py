@@ -1,4 +1,4 @@
-"""CPU: accuracy of the lean float64 log used by the kernels (csrc/lean_math.h), measured on the host against a
+"""CPU: accuracy of the lean float64 log / exp2 / sincospi used by the kernels (csrc/lean_math.h), measured on the host against a
 long double reference over 2e6 samples per argument domain.  The header is host+device, so this is the same
 source the kernel compiles (the device build contracts a*b+c into FMAs, which can only tighten the error).
 The rsqrt row exercises the host stand-in only (the device calls ocml rsqrt); it is reported, not asserted --
@@ -9,7 +9,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_lm_log_is_below_one_ulp(tmp_path):
+def test_lean_math_accuracy(tmp_path):
     exe = os.path.join(tmp_path, "lean_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
                            os.path.join(ROOT, "tests", "native", "lean_math_check.cpp")])
@@ -22,4 +22,12 @@ def test_lm_log_is_below_one_ulp(tmp_path):
         assert n == 2000000
         assert worst < 1.0, "%s: max error %.3f ulp" % (name, worst)      # fdlibm's bound for this algorithm
         assert mean < 0.3
+    n, worst, mean = rows["logc_sinr_ratio"]          # same algorithm, coefficients from the pinned block
+    assert worst < 1.0
+    for name in ("exp2_fading", "exp2_wide"):          # degree-13 Taylor of 2^r on |r| <= 1/2
+        n, worst, mean = rows[name]
+        assert worst < 1.0 and mean < 0.3, "%s: %.3f ulp" % (name, worst)
+    for name in ("sinpi_0_2", "cospi_0_2"):            # relative error, including next to the zeros
+        n, worst, mean = rows[name]
+        assert worst < 2.0 and mean < 0.4, "%s: %.3f ulp" % (name, worst)
     assert "rsqrt_dist2" in rows
