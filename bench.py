@@ -31,6 +31,23 @@ def algorithmic_bytes_per_env_step(U, B, Gr):
     return 48 * U + 2 * ((U + 7) // 8) + 96 * Gr + 16 * B + 45
 
 
+STEP_KERNEL = "env_kernel_packed<4, 2, true, true>"   # what rocprofv3 names the FAST step kernel of this workload
+
+
+def measured_traffic(envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_current.json), or None when
+    that file describes another kernel / batch size.  bench.py cannot run the profiler on itself."""
+    path = os.path.join(ROOT, "profiles", "traffic_current.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("kernel") != STEP_KERNEL or t.get("envs") != envs or t.get("n_ue") != N_UE or t.get("n_bs") != N_BS:
+        return None
+    return int(t["fetch_size_bytes_raw"]) + int(t["write_size_bytes_raw"])
+
+
 def cpu_baseline(target_seconds=12.0):
     """Times the CPU oracle (oracle/, kind 'port': scalar C restatement of the reference's step())
     on a bounded sample of the same workload, one shard per host thread."""
@@ -142,8 +159,8 @@ def main():
                                    "compact outputs, on-device Philox, one launch per step" % E,
                        "envs_per_gpu": E, "n_bs": N_BS, "n_ue": N_UE, "grid": GRID, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "env_kernel_packed<4,MODE_STEP,true>", "algorithmic_bytes_per_launch": b_step * E,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(E),
+                         "kernel": STEP_KERNEL, "algorithmic_bytes_per_launch": b_step * E,
                          "avg_launch_us": per_launch_s * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:
