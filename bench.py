@@ -48,7 +48,7 @@ def measured_traffic(envs):
     return int(t["fetch_size_bytes_raw"]) + int(t["write_size_bytes_raw"])
 
 
-def cpu_baseline(target_seconds=12.0):
+def cpu_baseline(target_seconds=15.0):
     """Times the CPU oracle (oracle/, kind 'port': scalar C restatement of the reference's step())
     on a bounded sample of the same workload, one shard per host thread."""
     import numpy as np
@@ -68,7 +68,7 @@ def cpu_baseline(target_seconds=12.0):
     for t in range(20):
         envs[0].step(acts[t])
     dt = (time.perf_counter() - t0) / 20
-    steps = int(max(50, min(20000, target_seconds / max(dt, 1e-9))))
+    steps = int(max(50, min(60000, target_seconds / max(dt, 1e-9))))
 
     def work(env):
         for t in range(steps):
