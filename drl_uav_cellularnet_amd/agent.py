@@ -1,0 +1,252 @@
+"""MLP actor-critic + synchronous A2C for the batched env, in PyTorch-ROCm (SURVEY.md section 8 f, row 1).
+
+Restated from the reference's TF1 code, which cannot run here (no tensorflow): **parity unpinned** -- the tests
+compare against NumPy restatements of the same formulas, not against TF outputs.
+  network   main.py:143-156   two separate trunks  N_S -> 200 relu6 -> 200 relu6 -> {N_A softmax | 1}
+            weights N(0, 0.1) (main.py:145), biases 0 (tf.layers.dense default)
+  loss      main.py:64-74     td = v_target - v;  c_loss = mean(td^2);
+                              a_loss = mean(-(log(p[a] + 1e-5) * stopgrad(td) + beta * H)),  H = -sum p log(p + 1e-5)
+  optimiser main.py:300-301   two tf.train.RMSPropOptimizer(lr=1e-4): decay 0.9, momentum 0, epsilon 1e-10 INSIDE
+                              the sqrt, mean-square accumulator initialised to ONES (TF1 semantics)
+  rollout   a2c_single_thread.py:107-133,153-186   T-step rollouts, n-step returns with gamma = 0.9 bootstrapped
+                              from v(s_T) (0 when done), one update per rollout over all workers' samples
+
+MI355X-side design: the observation is a count map with at most U + B non-zero cells (mobile_env.py:169-170), so
+the 50000 x 200 first layer is a gather-sum of weight rows over the COMPACT observation the env kernel already
+writes (ue_xy, serving, bs_xy) -- no dense (N, B+1, G, G) tensor is ever materialised on the training path.
+Gradients are synchronised with one flat all-reduce per update (RCCL over xGMI when launched one process per GPU).
+"""
+
+import torch
+import torch.nn.functional as F
+
+GAMMA = 0.9           # main.py:20
+ENTROPY_BETA = 0.001  # main.py:21
+LR_A = 1e-4           # main.py:22
+LR_C = 1e-4           # main.py:23
+HIDDEN = 200          # main.py:147-148
+
+
+def obs_to_indices(obs, grid_n, n_bs):
+    """Compact observation -> flat indices of the non-zero cells of the reference's raveled state
+    (np.ravel of (nBS+1, G, G), main.py:190,202):  plane 0 = UAV cells, plane 1+b = UEs served by UAV b."""
+    G = int(grid_n)
+    ue = obs["ue_xy"].long()
+    bs = obs["bs_xy"].long()
+    srv = obs["serving"].long()
+    ue_idx = (1 + srv) * (G * G) + ue[..., 0] * G + ue[..., 1]
+    bs_idx = bs[..., 0] * G + bs[..., 1]
+    return torch.cat([bs_idx, ue_idx], dim=-1)          # [N, B + U]; duplicates add, like the count map
+
+
+class ACNet(torch.nn.Module):
+    """Actor and critic trunks of main.py:143-156.  The first layers are stored as [N_S, 200] tables so that the
+    sparse path is an embedding-bag sum; ``forward_dense`` is the textbook matmul on the raveled dense state."""
+
+    def __init__(self, n_state, n_action, hidden=HIDDEN, seed=6):
+        super().__init__()
+        g = torch.Generator().manual_seed(int(seed))    # TENSOR_SEED = 6 (main.py:26); not TF's stream
+        def w(*shape):
+            return torch.nn.Parameter(torch.randn(*shape, generator=g) * 0.1)   # random_normal_initializer(0, .1)
+        def b(n):
+            return torch.nn.Parameter(torch.zeros(n))
+        self.n_state, self.n_action = int(n_state), int(n_action)
+        self.a_w1, self.a_b1 = w(n_state, hidden), b(hidden)
+        self.a_w2, self.a_b2 = w(hidden, hidden), b(hidden)
+        self.a_w3, self.a_b3 = w(hidden, n_action), b(n_action)
+        self.c_w1, self.c_b1 = w(n_state, hidden), b(hidden)
+        self.c_w2, self.c_b2 = w(hidden, hidden), b(hidden)
+        self.c_w3, self.c_b3 = w(hidden, 1), b(1)
+
+    def actor_params(self):
+        return [self.a_w1, self.a_b1, self.a_w2, self.a_b2, self.a_w3, self.a_b3]
+
+    def critic_params(self):
+        return [self.c_w1, self.c_b1, self.c_w2, self.c_b2, self.c_w3, self.c_b3]
+
+    def _heads(self, ha, hc):
+        ha = F.relu6(F.relu6(ha) @ self.a_w2 + self.a_b2)
+        hc = F.relu6(F.relu6(hc) @ self.c_w2 + self.c_b2)
+        a_prob = torch.softmax(ha @ self.a_w3 + self.a_b3, dim=-1)
+        v = hc @ self.c_w3 + self.c_b3
+        return a_prob, v
+
+    def forward(self, idx):
+        """idx: int64 [M, K] flat indices of the non-zero cells (obs_to_indices)."""
+        ha = F.embedding_bag(idx, self.a_w1, mode="sum") + self.a_b1
+        hc = F.embedding_bag(idx, self.c_w1, mode="sum") + self.c_b1
+        return self._heads(ha, hc)
+
+    def actor_only(self, idx):
+        ha = F.embedding_bag(idx, self.a_w1, mode="sum") + self.a_b1
+        ha = F.relu6(F.relu6(ha) @ self.a_w2 + self.a_b2)
+        return torch.softmax(ha @ self.a_w3 + self.a_b3, dim=-1)
+
+    def critic_only(self, idx):
+        hc = F.embedding_bag(idx, self.c_w1, mode="sum") + self.c_b1
+        hc = F.relu6(F.relu6(hc) @ self.c_w2 + self.c_b2)
+        return hc @ self.c_w3 + self.c_b3
+
+    def forward_dense(self, s):
+        """s: float [M, N_S], the raveled (nBS+1, G, G) state exactly as the reference feeds it (main.py:190)."""
+        return self._heads(s @ self.a_w1 + self.a_b1, s @ self.c_w1 + self.c_b1)
+
+
+def a2c_losses(a_prob, v, actions, v_target, beta=ENTROPY_BETA):
+    """(a_loss, c_loss) of main.py:64-74."""
+    td = v_target - v                                                     # :64
+    c_loss = (td ** 2).mean()                                             # :66
+    log_prob = torch.log(a_prob.gather(1, actions.view(-1, 1)) + 1e-5)    # :69
+    exp_v = log_prob * td.detach()                                        # :70
+    entropy = -(a_prob * torch.log(a_prob + 1e-5)).sum(dim=1, keepdim=True)  # :71-72
+    a_loss = (-(beta * entropy + exp_v)).mean()                           # :73-74
+    return a_loss, c_loss
+
+
+class TFRMSProp:
+    """tf.train.RMSPropOptimizer(learning_rate) as TF1 implements it (main.py:300-301):
+        ms <- decay * ms + (1 - decay) * g^2         (ms initialised to ONES)
+        var <- var - lr * g / sqrt(ms + epsilon)     (epsilon = 1e-10 inside the sqrt, momentum = 0)"""
+
+    def __init__(self, params, lr, decay=0.9, eps=1e-10):
+        self.params = list(params)
+        self.lr, self.decay, self.eps = float(lr), float(decay), float(eps)
+        self.ms = [torch.ones_like(p) for p in self.params]
+
+    @torch.no_grad()
+    def step(self):
+        grads = [p.grad for p in self.params]
+        torch._foreach_mul_(self.ms, self.decay)
+        torch._foreach_addcmul_(self.ms, grads, grads, value=1.0 - self.decay)
+        denom = torch._foreach_add(self.ms, self.eps)
+        torch._foreach_sqrt_(denom)
+        torch._foreach_addcdiv_(self.params, grads, denom, value=-self.lr)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def state_dict(self):
+        return {"ms": [m.clone() for m in self.ms], "lr": self.lr, "decay": self.decay, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        for m, s in zip(self.ms, sd["ms"]):
+            m.copy_(s)
+
+
+def nstep_returns(rewards, bootstrap, gamma=GAMMA):
+    """a2c_single_thread.py:176-183: value_estimate = r + gamma * value_estimate, backwards over the rollout.
+    rewards [T, N], bootstrap [N] (v(s_T), or 0 where the episode ended) -> targets [T, N]."""
+    T = rewards.shape[0]
+    out = torch.empty_like(rewards)
+    run = bootstrap
+    for t in range(T - 1, -1, -1):
+        run = rewards[t] + gamma * run
+        out[t] = run
+    return out
+
+
+def allreduce_mean_grads(params):
+    """One flat all-reduce of every gradient (sum / world size).  With one process per GPU and backend 'nccl' this is
+    RCCL over xGMI; a no-op without an initialised process group.  Returns the number of float32 elements reduced."""
+    import torch.distributed as dist
+
+    grads = [p.grad for p in params if p.grad is not None]
+    n = sum(g.numel() for g in grads)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return n
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+    return n
+
+
+class A2CRunner:
+    """Synchronous A2C over a BatchedMobiEnv: every env instance plays the role of one of the reference's workers
+    (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step."""
+
+    def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
+                 update_chunk=65536):
+        self.env = env
+        self.dev = env.device
+        self.G, self.B = env.grid_n, env.nBS
+        self.net = (net if net is not None else ACNet(env.observation_space_dim, env.action_space_dim, seed=seed)).to(self.dev)
+        self.opt_a = TFRMSProp(self.net.actor_params(), lr_a)
+        self.opt_c = TFRMSProp(self.net.critic_params(), lr_c)
+        self.T, self.gamma, self.beta = int(rollout), float(gamma), float(beta)
+        self.update_chunk = int(update_chunk)
+        self.gen = torch.Generator(device=self.dev).manual_seed(int(seed) + 1000 * int(env.env_id_base + 1))
+        self.idx = obs_to_indices(env.observation(), self.G, self.B)   # the reference starts from env.state (zeros,
+        self.ep_r = torch.zeros(env.n_envs, device=self.dev)           # a2c_single_thread.py:155); we use the real obs
+        self.running_r = None                                          # GLOBAL_RUNNING_R EMA, :169-172
+        self.stats = {}
+
+    @torch.no_grad()
+    def collect(self):
+        """One rollout: returns (idx [T,N,K], actions [T,N], rewards [T,N], bootstrap [N])."""
+        env, T, N = self.env, self.T, self.env.n_envs
+        K = self.idx.shape[1]
+        idx_buf = torch.empty((T, N, K), dtype=torch.int64, device=self.dev)
+        act_buf = torch.empty((T, N), dtype=torch.int64, device=self.dev)
+        rew_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
+        done = None
+        for t in range(T):
+            prob = self.net.actor_only(self.idx)                                     # choose_action, main.py:165-169
+            a = torch.multinomial(prob, 1, generator=self.gen).squeeze(1)
+            idx_buf[t], act_buf[t] = self.idx, a
+            obs, reward, done, _ = env.step(a)
+            rew_buf[t] = reward
+            self.idx = obs_to_indices(obs, self.G, self.B)
+        self.ep_r += rew_buf.sum(dim=0)
+        done = done.bool()
+        boot = self.net.critic_only(self.idx).squeeze(1)                             # :173-176
+        boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
+        if bool(done.any()):                                                         # :167-172 reset_worker
+            m = float(self.ep_r[done].mean())
+            self.running_r = m if self.running_r is None else 0.99 * self.running_r + 0.01 * m
+            self.ep_r[done] = 0.0
+            env.reset(mask=done)
+            self.idx = obs_to_indices(env.observation(), self.G, self.B)
+        return idx_buf, act_buf, rew_buf, boot
+
+    def update(self, idx_buf, act_buf, rew_buf, boot):
+        """One gradient step on all T*N samples (a2c_single_thread.py:120-133), chunked to bound activation memory."""
+        T, N, K = idx_buf.shape
+        target = nstep_returns(rew_buf, boot, self.gamma).reshape(T * N, 1)
+        idx, act = idx_buf.reshape(T * N, K), act_buf.reshape(T * N)
+        M = T * N
+        self.opt_a.zero_grad()
+        self.opt_c.zero_grad()
+        a_tot = c_tot = 0.0
+        for s in range(0, M, self.update_chunk):
+            e = min(M, s + self.update_chunk)
+            a_prob, v = self.net(idx[s:e])
+            a_loss, c_loss = a2c_losses(a_prob, v, act[s:e], target[s:e], self.beta)
+            w = (e - s) / M                                   # mean over the whole batch = weighted mean of chunks
+            ((a_loss + c_loss) * w).backward()                # disjoint parameter sets: same grads as two backward()s
+            a_tot += float(a_loss) * w
+            c_tot += float(c_loss) * w
+        n_red = allreduce_mean_grads(self.net.actor_params() + self.net.critic_params())
+        self.opt_a.step()
+        self.opt_c.step()
+        self.stats = {"a_loss": a_tot, "c_loss": c_tot, "mean_reward": float(rew_buf.mean()), "grad_elems": n_red,
+                      "running_r": self.running_r}
+        return self.stats
+
+    def train_rollout(self):
+        return self.update(*self.collect())
+
+
+def grad_allreduce_bytes(net):
+    return 4 * sum(p.numel() for p in net.parameters())
+
+
+def expected_param_count(n_state, n_action, hidden=HIDDEN):
+    """20 206 626 parameters at G = 100, 4 UAVs (80.8 MB float32)."""
+    actor = n_state * hidden + hidden + hidden * hidden + hidden + hidden * n_action + n_action
+    critic = n_state * hidden + hidden + hidden * hidden + hidden + hidden + 1
+    return actor + critic

@@ -1,0 +1,37 @@
+"""GPU: the A2C learner end to end on the HIP env (BASELINE config 3 shape, scaled down): rollouts through
+BatchedMobiEnv.step (FAST kernel), sparse first layer on the compact observation, one update per rollout."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_a2c_rollouts_and_updates_on_the_hip_env():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner, ACNet, obs_to_indices
+
+    N, T = 512, 10
+    env = BatchedMobiEnv(N, nBS=4, nUE=20, grid_n=100, max_step=25)        # short episodes: exercises done + masked reset
+    runner = A2CRunner(env, rollout=T, update_chunk=2048)
+    assert sum(p.numel() for p in runner.net.parameters()) == 20206626
+    # sparse path == dense path on the env's own dense observation
+    idx = obs_to_indices(env.observation(), 100, 4)
+    dense = env.dense_obs().reshape(N, -1)
+    with torch.no_grad():
+        p_s, v_s = runner.net(idx[:32])
+        p_d, v_d = runner.net.forward_dense(dense[:32])
+    torch.testing.assert_close(p_s, p_d, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(v_s, v_d, rtol=1e-4, atol=1e-4)
+    w0 = runner.net.a_w3.detach().clone()
+    steps = []
+    for it in range(4):
+        st = runner.train_rollout()
+        assert np.isfinite(st["a_loss"]) and np.isfinite(st["c_loss"]) and st["grad_elems"] == 20206626
+        steps.append(int(env.out["step_n"].max()))
+    assert steps == [10, 20, 5, 15]            # done at 25 (inside rollout 3) -> reset at its end, then 10 more
+    assert runner.running_r is not None        # an episode finished: GLOBAL_RUNNING_R bookkeeping ran
+    assert not torch.equal(w0, runner.net.a_w3.detach())
