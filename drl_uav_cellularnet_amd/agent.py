@@ -241,6 +241,37 @@ class A2CRunner:
         return self.update(*self.collect())
 
 
+ACTOR_KEYS = ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3")   # TF order: la/kernel, la/bias, la2/kernel, la2/bias, ap/kernel, ap/bias
+
+
+def save_actor_npz(net, path):
+    """Actor parameters, the content of the reference's Global_A_PARA.npz (main.py:265-269: np.savez(path,
+    SESS.run(a_params))).  The reference stores the ragged list as ONE pickled object array ('arr_0'); here the same
+    six arrays are stored under names, so loading never needs allow_pickle."""
+    import numpy as np
+
+    np.savez(path, **{k: getattr(net, k).detach().cpu().numpy() for k in ACTOR_KEYS})
+
+
+def load_actor_npz(net, path):
+    """Inverse of save_actor_npz (main_test.py:11-26 assigns the six arrays to the actor variables in order)."""
+    import numpy as np
+
+    with np.load(path, allow_pickle=False) as z:
+        missing = [k for k in ACTOR_KEYS if k not in z.files]
+        if missing:
+            raise ValueError("not an actor checkpoint written by save_actor_npz (missing %s); the reference's own "
+                             "Global_A_PARA.npz is a pickled object array and is not loaded" % missing)
+        with torch.no_grad():
+            for k in ACTOR_KEYS:
+                p = getattr(net, k)
+                a = torch.as_tensor(z[k])
+                if tuple(a.shape) != tuple(p.shape):
+                    raise ValueError("%s: checkpoint shape %s != network shape %s" % (k, tuple(a.shape), tuple(p.shape)))
+                p.copy_(a.to(p.device, p.dtype))
+    return net
+
+
 def grad_allreduce_bytes(net):
     return 4 * sum(p.numel() for p in net.parameters())
 

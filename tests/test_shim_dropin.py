@@ -155,3 +155,33 @@ def test_unsupported_models_behave_like_the_reference():
         MobiEnvironment(4, 40, 100, "in_coverage")
     with pytest.raises(AssertionError):                                                  # mobile_env.py:84
         MobiEnvironment(4, 40, 100, "read_trace", "")
+
+
+def test_gradient_heuristic_runs_on_the_shim_and_leaves_the_env_untouched():
+    """gradient.py:14-37,56-86: look-ahead on a deepcopy + step_test; actions use digits 0..3 only."""
+    _need_gpu()
+    from drl_uav_cellularnet_amd import MobiEnvironment
+    from drl_uav_cellularnet_amd.heuristics import choose_act_gradient, run_gradient_policy, side_means
+
+    env = MobiEnvironment(4, 40, 100, seed=21)
+    env.reset()
+    snap = (env.ueLoc.copy(), env.bsLoc.copy(), env.channel.current_BS_sinr.copy(), env.step_n)
+    a = choose_act_gradient(env)
+    np.testing.assert_array_equal(env.ueLoc, snap[0])
+    np.testing.assert_array_equal(env.bsLoc, snap[1])
+    np.testing.assert_array_equal(env.channel.current_BS_sinr, snap[2])
+    assert env.step_n == snap[3]
+    digits = [(a // 5 ** k) % 5 for k in (3, 2, 1, 0)]
+    assert all(0 <= d <= 3 for d in digits)
+    # independent evaluation of the rule on the same look-ahead state
+    import copy
+
+    v = copy.deepcopy(env)
+    v.step_test(624, False)
+    want = [int(np.nanargmin(side_means(v.channel.current_BS_sinr, v.ueLoc, v.bsLoc[i]))) for i in range(4)]
+    assert digits == want
+    rewards, actions = run_gradient_policy(MobiEnvironment(4, 40, 100, seed=21), 40)
+    assert rewards.shape == (40,) and np.isfinite(rewards).all() and (rewards >= -1).all()
+    r2, a2 = run_gradient_policy(MobiEnvironment(4, 40, 100, seed=21), 40)
+    np.testing.assert_array_equal(actions, a2)                          # deterministic given the seed
+    np.testing.assert_array_equal(rewards, r2)
