@@ -228,8 +228,8 @@ class A2CRunner:
             a_loss, c_loss = a2c_losses(a_prob, v, act[s:e], target[s:e], self.beta)
             w = (e - s) / M                                   # mean over the whole batch = weighted mean of chunks
             ((a_loss + c_loss) * w).backward()                # disjoint parameter sets: same grads as two backward()s
-            a_tot += float(a_loss) * w
-            c_tot += float(c_loss) * w
+            a_tot += float(a_loss.detach()) * w
+            c_tot += float(c_loss.detach()) * w
         n_red = allreduce_mean_grads(self.net.actor_params() + self.net.critic_params())
         self.opt_a.step()
         self.opt_c.step()

@@ -32,6 +32,8 @@ def test_a2c_rollouts_and_updates_on_the_hip_env():
         st = runner.train_rollout()
         assert np.isfinite(st["a_loss"]) and np.isfinite(st["c_loss"]) and st["grad_elems"] == 20206626
         steps.append(int(env.out["step_n"].max()))
-    assert steps == [10, 20, 5, 15]            # done at 25 (inside rollout 3) -> reset at its end, then 10 more
+    # done turns true at step 25 inside rollout 3 and stays true (step_n >= MAXSTEP, no auto-reset); like Worker.work
+    # (a2c_single_thread.py:158-172) the rollout runs on to step 30 and the env is reset AFTER it -> step_n 0, then 10
+    assert steps == [10, 20, 0, 10]
     assert runner.running_r is not None        # an episode finished: GLOBAL_RUNNING_R bookkeeping ran
     assert not torch.equal(w0, runner.net.a_w3.detach())
