@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path with several ranks sharing one GPU)")
+    ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     args = ap.parse_args()
 
     import torch
@@ -105,8 +108,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.force_device is not None:
+            local_rank = args.force_device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -144,7 +152,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
-    elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=dev)   # slowest rank (identity at N=1)
+    elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=dev if args.backend == "nccl" else None)  # slowest rank
 
     if rank == 0:
         per_launch_s = gpu_ms * 1e-3 / K  # average launch-to-launch time of the step kernel (HIP events)
