@@ -230,6 +230,23 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_obs_dense(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def sinr_area(self, fading=None, dtype=torch.float32):
+        """LTEChannel.GetSinrInArea (channel.py:411-433) for every env: [N, G, G] dB, nearest-UAV SINR per cell with
+        fresh shadowing (row / column 0 are 0, as in the reference).  ``fading``: injected draws [N, (G-1)^2, B]."""
+        N, B, G = self.n_envs, self.nBS, self.grid_n
+        out = torch.empty((N, G, G), dtype=dtype, device=self.device)
+        fptr = None
+        if fading is not None:
+            f = self._dev64(fading, (N, (G - 1) * (G - 1), B))
+            self._keep = [f]
+            fptr = f.data_ptr()
+        o32 = out.data_ptr() if dtype == torch.float32 else None
+        o64 = out.data_ptr() if dtype == torch.float64 else None
+        if o32 is None and o64 is None:
+            raise ValueError("dtype must be torch.float32 or torch.float64")
+        _capi.check(self._lib.uavenv_sinr_area(self._h, fptr, o32, o64, self._stream()))
+        return out
+
     # ---- state blob: copy.deepcopy(env) (gradient.py:15) / checkpoint --------------------------------
     def get_state(self):
         """Whole persistent state as one host uint8 array (synchronises)."""

@@ -402,6 +402,33 @@ extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     return UAVENV_OK;
 }
 
+extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float *out_f32_dev, double *out_f64_dev,
+                                void *stream) {
+    if (!h || (!out_f32_dev && !out_f64_dev)) return fail(UAVENV_E_INVALID, "sinr_area: null handle or no output buffer");
+    DeviceGuard guard(h->device);
+    const KParams &k = h->kp;
+    const size_t n = (size_t)k.N * k.G * k.G;
+    if (out_f32_dev) HIP_TRY(hipMemsetAsync(out_f32_dev, 0, n * sizeof(float), (hipStream_t)stream));
+    if (out_f64_dev) HIP_TRY(hipMemsetAsync(out_f64_dev, 0, n * sizeof(double), (hipStream_t)stream));
+    const long long total = k.N * (long long)(k.G - 1) * (k.G - 1);
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define UAVENV_AREA(BT_)                                                                                              \
+    do {                                                                                                              \
+        if (h->plc) hipLaunchKernelGGL((sinr_area_kernel<BT_, true>), grid, blk, 0, s, k, fading_inj_dev, out_f32_dev, out_f64_dev);   \
+        else hipLaunchKernelGGL((sinr_area_kernel<BT_, false>), grid, blk, 0, s, k, fading_inj_dev, out_f32_dev, out_f64_dev);         \
+    } while (0)
+    switch (h->bt) {
+        case 4: UAVENV_AREA(4); break;
+        case 8: UAVENV_AREA(8); break;
+        case 16: UAVENV_AREA(16); break;
+        default: UAVENV_AREA(32); break;
+    }
+#undef UAVENV_AREA
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout) {
     if (!h || !layout) return fail(UAVENV_E_INVALID, "state_layout: null argument");
     *layout = h->lay;

@@ -760,4 +760,80 @@ __global__ __launch_bounds__(256) void obs_scatter_kernel(long long N, int U, in
     atomicAdd(&obs[(e * (B + 1) + pl) * plane + (long long)x * G + y], 1.0f);
 }
 
+// ================================================================================================
+// LTEChannel.GetSinrInArea (channel.py:411-433): DL SINR of the NEAREST UAV at every cell (x, y) in [1, G-1]^2 with a
+// fresh shadowing draw per (cell, UAV).  One thread per (env, cell); the outputs are zero-filled by the caller, so
+// row / column 0 stay 0 like np.zeros((gridX, gridY)).  Same linear-domain arithmetic as rx_power().
+// fading_inj: [N, (G-1)^2, B] in the reference's call order per cell (interferers ascending, then the nearest UAV).
+// ================================================================================================
+template <int BT, bool PLC>
+__global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const double *fading_inj, float *out32,
+                                                        double *out64) {
+    const int B = p.B, G = p.G, W = G - 1;
+    const long long cells = (long long)W * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.N * cells) return;
+    const long long e = t / cells;
+    const long long c = t - e * cells;
+    const int x = 1 + (int)(c / W), y = 1 + (int)(c % W);            // :416-417 range(xMin, xMax) x range(yMin, yMax)
+    const LeanCoef C = lm_make_coef();
+    const HotConst H = make_hot(p);
+    int d2i[BT];
+    int near = 0;                                                   // :418-422 np.argmin(dist): first minimum
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        int v = 0x7FFFFFFF;
+        if (b < B) {
+            const int dx = x - p.bs_xy[(e * B + b) * 2], dy = y - p.bs_xy[(e * B + b) * 2 + 1];
+            v = dx * dx + dy * dy;                                   // distance ignores z (GetDistance, :220-226)
+        }
+        d2i[b] = v;
+    }
+    int best_d2 = d2i[0];
+#pragma unroll
+    for (int b = 1; b < BT; ++b)
+        if (b < B && d2i[b] < best_d2) { best_d2 = d2i[b]; near = b; }
+
+    double interf = 0.0, own = 0.0;
+#pragma unroll
+    for (int b2 = 0; b2 < BT; b2 += 2) {
+        double f0 = 0.0, f1 = 0.0;
+        if (b2 < B) {
+            if (fading_inj != nullptr) {
+                // position of UAV b in the reference's draw order for this cell: others ascending, `near` last
+                const long long base = (e * cells + c) * B;
+                const int b0 = b2, b1 = b2 + 1;
+                f0 = fading_inj[base + (b0 == near ? B - 1 : (b0 < near ? b0 : b0 - 1))];
+                if (b1 < B) f1 = fading_inj[base + (b1 == near ? B - 1 : (b1 < near ? b1 : b1 - 1))];
+            } else {
+                double u0, u1;
+                philox_u2(p, (uint32_t)e, p.tick[e], (uint32_t)(c * ((B + 1) >> 1) + (b2 >> 1)), DOM_AREA, u0, u1);
+                const double tt = -2.0 * lm_logc(1.0 - u0, C);
+                const double r = (tt > 0.0) ? tt * lm_rsqrt(tt) : 0.0;
+                double sa, ca;
+                lm_sincospi(2.0 * u1, C, &sa, &ca);
+                f0 = H.sh_mean + H.sh_sd * (r * ca);
+                f1 = H.sh_mean + H.sh_sd * (r * sa);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b2 + k;
+            if (b < BT && b < B) {
+                const double f = (k == 0) ? f0 : f1;
+                const double d2 = (H.gw * H.gw) * (double)d2i[b];
+                double g;
+                if (PLC) { const double rinv = lm_rsqrt(d2); g = H.k_pl * lm_exp2(H.c_exp * f, C) * (rinv * rinv * rinv); }
+                else g = H.k_pl * lm_exp2(H.c_exp * f - H.pl_exp_ln * lm_logc(d2, C), C);
+                if (!(d2 > H.pl_dis2)) g = H.k_0 * lm_exp2(H.c_exp * f, C);
+                if (b == near) own = g; else interf += g;            // :423-427 P_interf += P * gain, ascending
+            }
+        }
+    }
+    const double s = H.db_per_ln * lm_logc(own / (H.noise + interf), C);   // :429-431
+    const long long o = e * (long long)G * G + (long long)x * G + y;
+    if (out32) out32[o] = (float)s;
+    if (out64) out64[o] = s;
+}
+
 }  // namespace uavk

@@ -12,7 +12,7 @@ Differences, all deliberate and documented in DESIGN.md:
    the tail when nUE < 40 (SURVEY.md N1) -- identical for the nUE = 40 every reference script uses;
  * mobility models no reference driver selects are not provided: ``in_coverage`` raises NotImplementedError,
    ``random_waypoint`` is not defined in the reference either (mobile_env.py:73 -> NameError there);
- * rendering (``render`` / ``plot_sinr_map``) and ``channel.GetSinrInArea`` are outside the hot path.
+ * rendering (``render`` / ``plot_sinr_map``) is outside the hot path.
 """
 import copy
 import sys
@@ -46,9 +46,14 @@ class _ChannelView:
         """(nBS, G, G) float64 count map of the serving UAV of every UE (channel.py:387-409)."""
         return np.array(self._o._dense()[1:])
 
-    def GetSinrInArea(self, bsLoc):
-        raise NotImplementedError("GetSinrInArea (channel.py:411-433) is an evaluation plot helper outside the "
-                                  "step()/reset() hot path; see DESIGN.md 'out of scope / next'")
+    def GetSinrInArea(self, bsLoc=None):
+        """(G, G) float64 dB map of the nearest-UAV DL SINR with fresh shadowing (channel.py:411-433), for the env's
+        current UAV cells -- which is what every caller passes (main_test.py:89: info.bs_loc)."""
+        import torch
+
+        if bsLoc is not None and not np.array_equal(np.asarray(bsLoc)[:, :2], self._o.bsLoc[:, :2]):
+            raise NotImplementedError("GetSinrInArea is evaluated for the env's current UAV cells only")
+        return self._o._env.sinr_area(dtype=torch.float64)[0].cpu().numpy()
 
 
 class MobiEnvironment:

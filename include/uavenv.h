@@ -134,6 +134,12 @@ int uavenv_reset_trace(uavenv_t *h, const uint8_t *mask_dev, const int16_t *ue_x
  * channel.py:387-409).  Full rewrite of obs_dev. */
 int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream);
 
+/* LTEChannel.GetSinrInArea (channel.py:411-433) for the UAV cells currently in the state: per-cell DL SINR [dB] of the
+ * nearest UAV with fresh shadowing.  Outputs [N,G,G] (row/column 0 = 0); at least one of out_f32_dev / out_f64_dev.
+ * fading_inj_dev: [N,(G-1)^2,B] draws in the reference's call order per cell (interferers ascending, then the nearest
+ * UAV), or NULL for the on-device Philox stream. */
+int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float *out_f32_dev, double *out_f64_dev, void *stream);
+
 /* copy.deepcopy(env) (gradient.py:15) / checkpointing: the whole persistent state as one blob. */
 int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout);
 int uavenv_get_state(uavenv_t *h, void *dst, int dst_is_device, void *stream);

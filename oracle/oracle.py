@@ -199,6 +199,14 @@ class OracleEnv:
                               C.byref(self.out))
         return self.o
 
+    def sinr_area(self, fading=None):
+        """GetSinrInArea (channel.py:411-433) -> float64 [N, G, G]."""
+        G, W = self.cfg.grid, self.cfg.grid - 1
+        out = np.zeros((self.N, G, G), np.float64)
+        f = None if fading is None else np.ascontiguousarray(np.asarray(fading, np.float64).reshape(self.N, W * W, self.B))
+        lib().uavo_sinr_area(C.byref(self.cfg), C.byref(self.st), _ptr(f), _ptr(out))
+        return out
+
     def obs_dense(self):
         G = self.cfg.grid
         obs = np.zeros((self.N, self.B + 1, G, G), np.float32)

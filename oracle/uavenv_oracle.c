@@ -42,7 +42,7 @@ void uavo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 
 enum { /* Philox counter word 3: draw site */
     DOM_FADING = 1, DOM_HEADING = 2, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
-    DOM_INIT_UE_A = 5, DOM_INIT_UE_B = 6, DOM_INIT_G_A = 7, DOM_INIT_G_B = 8, DOM_INIT_G_C = 9
+    DOM_INIT_UE_A = 5, DOM_INIT_UE_B = 6, DOM_INIT_G_A = 7, DOM_INIT_G_B = 8, DOM_INIT_G_C = 9, DOM_AREA = 10
 };
 
 /* 53-bit uniform in [0,1) from two 32-bit words (same construction as numpy's random_double) */
@@ -514,6 +514,59 @@ int uavo_step_trace(const UavoConfig *cfg, UavoState *st, const int64_t *actions
         channel_update(cfg, st, e, inj, out, fading, sinr, cur);
     }
     free(fading);
+    return 0;
+}
+
+/* ---- LTEChannel.GetSinrInArea, channel.py:411-433 -------------------------------------------------- */
+int uavo_sinr_area(const UavoConfig *cfg, const UavoState *st, const double *fading_inj, double *out) {
+    const int B = cfg->n_bs, G = cfg->grid, HB = (B + 1) / 2, W = G - 1;
+    const double P_bs_watt = pow(10.0, cfg->p_bs_dbm / 10.0) * 1e-3;
+    const double noise_watt = pow(10.0, cfg->noise_dbm / 10.0) * 1e-3;
+    double f[UAVO_MAX_BS];
+    for (int64_t e = 0; e < st->n_envs; ++e) {
+        const int32_t *bs = st->bs_xy + e * 2 * B;
+        double *o = out + e * (int64_t)G * G;
+        memset(o, 0, sizeof(double) * (size_t)G * G);                      /* :413 np.zeros((gridX, gridY)) */
+        for (int x = 1; x < G; ++x)                                          /* :416 range(xMin, xMax) */
+            for (int y = 1; y < G; ++y) {                                    /* :417 */
+                const int64_t cell = (int64_t)(x - 1) * W + (y - 1);
+                int near = 0;                                                /* :418-422 argmin of GetDistance (first minimum) */
+                double dmin = 0;
+                for (int b = 0; b < B; ++b) {
+                    double dx = (double)x * cfg->grid_width - (double)bs[2 * b] * cfg->grid_width;
+                    double dy = (double)y * cfg->grid_width - (double)bs[2 * b + 1] * cfg->grid_width;
+                    double d = sqrt(dx * dx + dy * dy);
+                    if (b == 0 || d < dmin) { dmin = d; near = b; }
+                }
+                /* shadowing of UAV b at this cell */
+                if (fading_inj) {                                            /* call order :425-429: others ascending, own last */
+                    int k = 0;
+                    for (int b = 0; b < B; ++b) if (b != near) f[b] = fading_inj[(e * W * W + cell) * B + k++];
+                    f[near] = fading_inj[(e * W * W + cell) * B + (B - 1)];
+                } else {
+                    for (int p = 0; p < HB; ++p) {
+                        double t[2];
+                        philox_u2(st, e, st->tick[e], (uint32_t)(cell * HB + p), DOM_AREA, t);
+                        double r = sqrt(-2.0 * log(1.0 - t[0])), a = TWO_PI_NP * t[1];
+                        f[2 * p] = cfg->shadow_mean + cfg->shadow_sd * (r * cos(a));
+                        if (2 * p + 1 < B) f[2 * p + 1] = cfg->shadow_mean + cfg->shadow_sd * (r * sin(a));
+                    }
+                }
+                double P_interf = 0;                                         /* :423 */
+                double own = 0;
+                for (int b = 0; b < B; ++b) {
+                    double dx = (double)x * cfg->grid_width - (double)bs[2 * b] * cfg->grid_width;
+                    double dy = (double)y * cfg->grid_width - (double)bs[2 * b + 1] * cfg->grid_width;
+                    double d = sqrt(dx * dx + dy * dy);
+                    double loss = 0;
+                    if (d > cfg->pl_dis) loss = cfg->pl_a + cfg->pl_b * log10(d);
+                    double gain = pow(10.0, (cfg->antenna_gain - loss - f[b] - cfg->eq_loss) / 10.0);   /* :237-247 */
+                    if (b == near) own = gain; else P_interf += P_bs_watt * gain;        /* :425-427 sequential += */
+                }
+                double s = P_bs_watt * own / (noise_watt + P_interf);        /* :429 */
+                o[(int64_t)x * G + y] = 10 * log10(s);                       /* :431 */
+            }
+    }
     return 0;
 }
 

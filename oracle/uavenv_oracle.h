@@ -98,6 +98,11 @@ int uavo_step_trace(const UavoConfig *cfg, UavoState *st, const int64_t *actions
 int uavo_reset_trace(const UavoConfig *cfg, UavoState *st, const uint8_t *mask, const int16_t *ue_xy_in,
                      const UavoInject *inj, UavoOut *out);
 int uavo_obs_dense(const UavoConfig *cfg, const UavoState *st, float *obs);
+/* LTEChannel.GetSinrInArea (channel.py:411-433): per-cell DL SINR of the NEAREST UAV with fresh fading, for the UAV
+ * cells currently in st->bs_xy.  out [N,G,G] float64 (row/column 0 stay 0: the loops start at xMin = yMin = 1).
+ * fading_inj [N,(G-1)*(G-1),B] in the reference's call order per cell (interferers ascending, then the serving UAV),
+ * or NULL for Philox (draw site DOM_AREA, time = st->tick). */
+int uavo_sinr_area(const UavoConfig *cfg, const UavoState *st, const double *fading_inj, double *out);
 void uavo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double uavo_np_pairwise_sum(const double *a, int64_t n);
 

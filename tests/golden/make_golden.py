@@ -360,6 +360,30 @@ def run_trace_scenario(name, seed, n_steps, trace_len):
     print("%-34s E=%d trace rows=%d handovers=n/a  %.1f KB" % (name, E, trace_len, os.path.getsize(path) / 1024.0))
 
 
+def run_area_scenario(name, seed, grid, bs_cells):
+    """LTEChannel.GetSinrInArea (channel.py:411-433) for given UAV cells; the draws are (G-1)^2 * B normals in the
+    reference's call order (interferers ascending, then the nearest UAV) and are regenerated from the seed."""
+    mods = load_reference()
+    chm = mods["channel"]
+    B, U = len(bs_cells), 8
+    bs = np.concatenate([np.array(bs_cells, dtype=int), np.full((B, 1), 10, dtype=int)], axis=1)
+    ue = np.zeros((U, 3), dtype=int) + 5
+    np.random.seed(seed + 5000)
+    ch = chm.LTEChannel(U, B, [1, grid, 1, grid], ue, bs)      # its own draws come from another seed
+    np.random.seed(seed)
+    with Recorder(mods) as rec:
+        sinr = ch.GetSinrInArea(bs)
+    normals = np.array(rec.normal_log)
+    W = grid - 1
+    assert normals.size == W * W * B and sinr.shape == (grid, grid)
+    rs = np.random.RandomState(seed)
+    assert np.array_equal(rs.normal(0.0, 2.0, size=(W * W, B)).ravel(), normals)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, seed=seed, grid=grid, n_bs=B, bs_xy=np.array(bs_cells, np.int32), sinr_area=sinr)
+    print("%-34s cells=%d B=%d  min %.1f dB max %.1f dB  %.1f KB" % (name, W * W, B, sinr[1:, 1:].min(), sinr.max(),
+                                                                  os.path.getsize(path) / 1024.0))
+
+
 def probe_last_ue(probe, W):
     s = probe.snaps[W - 1]
     return np.stack([s["x"], s["y"]], axis=1).astype(int)
@@ -420,7 +444,11 @@ def scenario_list():
     def s6():
         run_trace_scenario("ref_trace_4x40_g100_seed6", 6, 240, 260)
 
-    sc["s1"], sc["s2"], sc["s3"], sc["s4"], sc["s5"], sc["s6"] = s1, s2, s3, s4, s5, s6
+    def s7():
+        run_area_scenario("ref_area_4bs_g100_seed7", 7, 100, [(25, 25), (25, 75), (75, 25), (75, 75)])
+        run_area_scenario("ref_area_5bs_g40_seed8", 8, 40, [(3, 3), (9, 31), (20, 20), (20, 21), (37, 12)])
+
+    sc["s1"], sc["s2"], sc["s3"], sc["s4"], sc["s5"], sc["s6"], sc["s7"] = s1, s2, s3, s4, s5, s6, s7
     return sc
 
 

@@ -289,3 +289,45 @@ def test_bad_arguments_fail_loudly():
     env = BatchedMobiEnv(8)
     with pytest.raises(ValueError):
         env.step(torch.zeros(7, dtype=torch.int64, device=env.device))
+
+
+@pytest.mark.parametrize("name", ["ref_area_4bs_g100_seed7", "ref_area_5bs_g40_seed8"])
+def test_hip_sinr_area_matches_reference(name):
+    """LTEChannel.GetSinrInArea (channel.py:411-433), injected draws, against the map the real reference produced."""
+    import os
+
+    torch = _torch()
+    from conftest import GOLDEN_DIR
+
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
+        seed, G, B, bs, want = int(z["seed"]), int(z["grid"]), int(z["n_bs"]), z["bs_xy"], z["sinr_area"]
+    N = 3
+    env = _make(N, nBS=B, nUE=8, grid_n=G, groups=[2, 2, 2, 2], bs_init=[tuple(r) for r in bs], construct=False)
+    env.init()                                                       # UAVs on bs_init
+    fading = np.random.RandomState(seed).normal(0.0, 2.0, size=((G - 1) * (G - 1), B))
+    f = np.broadcast_to(fading, (N,) + fading.shape)
+    got64 = env.sinr_area(fading=f, dtype=torch.float64).cpu().numpy()
+    got32 = env.sinr_area(fading=f, dtype=torch.float32).cpu().numpy()
+    for n in range(N):
+        assert (got64[n][0] == 0).all() and (got64[n][:, 0] == 0).all()
+        np.testing.assert_allclose(got64[n], want, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(got32[n], want.astype(np.float32), rtol=F32_RTOL, atol=0)
+
+
+def test_hip_sinr_area_matches_oracle_on_philox_streams():
+    torch = _torch()
+    from oracle import oracle as O
+
+    N, B, U, G = 5, 4, 20, 64
+    env = _make(N, nBS=B, nUE=U, grid_n=G, seed=4242, env_id_base=7)
+    orc = O.OracleEnv(O.make_config(B, U, G, groups=[5, 5, 5, 5]), N, seed=4242, env_id_base=7)
+    orc.construct()
+    rs = np.random.RandomState(1)
+    for t in range(6):                                               # move the UAVs around first
+        a = rs.randint(0, 625, N).astype(np.int64)
+        env.step(torch.as_tensor(a, device=env.device))
+        orc.step(a)
+    got = env.sinr_area(dtype=torch.float64).cpu().numpy()
+    want = orc.sinr_area()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert float(np.abs(want).max()) > 10.0

@@ -98,3 +98,24 @@ def test_oracle_replays_reference_read_trace():
 
     replay_trace_fixture(env, fx, 1, check)
     assert seen["n"] == len(fx["ev_kind"]) + 1
+
+
+import pytest
+
+
+@pytest.mark.parametrize("name", ["ref_area_4bs_g100_seed7", "ref_area_5bs_g40_seed8"])
+def test_oracle_sinr_area_matches_reference(name):
+    """GetSinrInArea (channel.py:411-433): nearest-UAV SINR map with fresh fading, captured from the reference."""
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
+        seed, G, B, bs, want = int(z["seed"]), int(z["grid"]), int(z["n_bs"]), z["bs_xy"], z["sinr_area"]
+    cfg = O.make_config(B, 8, G, groups=[2, 2, 2, 2], bs_init=bs)
+    env = O.OracleEnv(cfg, 1)
+    env.init()                                                  # puts the UAVs on bs_init
+    fading = np.random.RandomState(seed).normal(0.0, 2.0, size=((G - 1) * (G - 1), B))
+    got = env.sinr_area(fading=fading[None])[0]
+    assert (got[0] == 0).all() and (got[:, 0] == 0).all()       # loops start at 1 (channel.py:416-417)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)

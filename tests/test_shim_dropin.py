@@ -185,3 +185,20 @@ def test_gradient_heuristic_runs_on_the_shim_and_leaves_the_env_untouched():
     r2, a2 = run_gradient_policy(MobiEnvironment(4, 40, 100, seed=21), 40)
     np.testing.assert_array_equal(actions, a2)                          # deterministic given the seed
     np.testing.assert_array_equal(rewards, r2)
+
+
+def test_shim_get_sinr_in_area_shape_and_determinism():
+    """main_test.py:89: test_env.channel.GetSinrInArea(info.bs_loc) -> (G, G) float64 map."""
+    _need_gpu()
+    from drl_uav_cellularnet_amd import MobiEnvironment
+
+    env = MobiEnvironment(4, 40, 100, seed=3)
+    env.reset()
+    _, _, _, info = env.step_test(17)
+    m = env.channel.GetSinrInArea(info.bs_loc)
+    assert m.shape == (100, 100) and m.dtype == np.float64
+    assert (m[0] == 0).all() and (m[:, 0] == 0).all() and np.isfinite(m).all()
+    bx, by = info.bs_loc[0][:2]
+    assert m[bx, by] > 60.0                                           # a cell under a UAV: d = 0 -> loss 0 (SURVEY Q2)
+    with pytest.raises(NotImplementedError):
+        env.channel.GetSinrInArea(info.bs_loc + 1)
