@@ -59,7 +59,9 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libuavenv.so")
+    """In-tree library; UAVENV_LIB overrides it (A/B runs of kernel build variants, see tools/ab_variants.sh)."""
+    return os.environ.get("UAVENV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                        "libuavenv.so")
 
 
 class UavEnvError(RuntimeError):

@@ -220,6 +220,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.bs_init = h->bs_init_dev;
     k.act_pow = h->act_pow_dev;
     k.gid_of_u = h->gid_dev;
+    u32div_gen((uint32_t)cfg->n_act, &k.div_magic, &k.div_shift);   // exact digit extraction (intdiv.h)
     k.act32 = (n_joint <= 0xFFFFFFFFll) ? 1 : 0;  // 32-bit digit extraction when every joint action fits
     // Packed kernel: floor(64/U) env instances per wavefront; needs the group / UAV owner lanes inside a slot.
     h->packed = (cfg->n_ue <= 64) && (cfg->n_ue >= cfg->n_bs) && (cfg->n_ue >= cfg->n_groups);
@@ -428,6 +429,15 @@ extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }
+
+#ifdef UAVENV_STAMPS
+// Diagnostic builds only (not in include/uavenv.h): where the kernels drop their s_memtime stamps.
+extern "C" int uavenv_debug_set_stamp_buffer(uavenv_t *h, void *dev_ptr) {
+    if (!h) return fail(UAVENV_E_INVALID, "debug_set_stamp_buffer: null handle");
+    h->kp.dbg = (unsigned long long *)dev_ptr;
+    return UAVENV_OK;
+}
+#endif
 
 extern "C" int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout) {
     if (!h || !layout) return fail(UAVENV_E_INVALID, "state_layout: null argument");

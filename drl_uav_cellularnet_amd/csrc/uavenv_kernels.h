@@ -22,12 +22,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "intdiv.h"
 #include "lean_math.h"
 #include "philox.h"
 
 namespace uavk {
 
-constexpr int kWavesPerBlock = 4;
+#ifndef UAVENV_WAVES_PER_BLOCK
+#define UAVENV_WAVES_PER_BLOCK 4   // wavefronts per workgroup of the env kernels (build-time knob for A/B runs)
+#endif
+constexpr int kWavesPerBlock = UAVENV_WAVES_PER_BLOCK;
 constexpr int kMaxGroups = 16;
 constexpr int kMaxBs = 32;
 constexpr int kMaxEpw = 8;  // env instances per wavefront (packed kernel)
@@ -60,6 +64,7 @@ struct OutPtrs {
 struct KParams {
     // shape / constants
     int U, B, Gr, G, W64, epw, act32;
+    uint32_t div_magic, div_shift;   // exact a / n_act by multiply-shift (intdiv.h)
     int group_start[kMaxGroups + 1];
     int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
     double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
@@ -78,6 +83,7 @@ struct KParams {
     const double *inj_theta, *inj_group, *inj_fading;
     const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
     OutPtrs out;
+    unsigned long long *dbg;   // diagnostic builds only (UAVENV_STAMPS): [waves][8] s_memtime stamps
 };
 
 struct InitParams {
@@ -89,6 +95,21 @@ struct InitParams {
     unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy; const int32_t *bs_init;
     const double *u_x, *u_y, *u_th, *u_g;
 };
+
+// In-kernel phase stamps (diagnostic build -DUAVENV_STAMPS only; MI355X guide, "In-kernel stamps"): one asm
+// statement per stamp with its own lgkmcnt(0), scheduling barriers around it.  Values go to p.dbg, never to outputs.
+#ifdef UAVENV_STAMPS
+#define UAV_STAMP(var)                                                             \
+    do {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+#define UAV_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define UAV_STAMP(var) do { } while (0)
+#define UAV_DRAIN_VM() do { } while (0)
+#endif
 
 // ================================================================================================
 // shared device helpers (both env kernels run exactly this arithmetic)
@@ -152,6 +173,57 @@ __device__ __forceinline__ void uav_propose(const KParams &p, int xi, int yi, in
     else if (di == 6) { if (xi - sl > xMin) nx = xi - sl; }
     else if (di == 7) { if (yi + sl < yMax) ny = yi + sl; }
     else if (di == 8) { if (yi - sl > yMin) ny = yi - sl; }
+}
+
+// BS_move replayed serially in registers by EVERY lane for its own env (BT <= 8: B*(B-1) integer checks, no
+// cross-lane traffic).  profiles/r01_v8: the cooperative version (one UAV per lane, 3 ds_bpermute + 1 ballot per
+// sequential round, LDS staging + barrier) took 21 % of a wavefront's lifetime, more than twice the mobility tick.
+// Semantics as ue_mobility.py:191-271: UAV i proposes from digit i (most significant digit -> UAV 0, :310-336), the
+// collision test uses i's PRE-move cell against the already-updated cells of j < i and the old cells of j > i.
+template <int BT>
+__device__ __forceinline__ void bs_move_serial(const KParams &p, unsigned a, int (&bsx)[BT], int (&bsy)[BT]) {
+    const int B = p.B;
+    const unsigned n = (unsigned)p.n_act;
+    const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;      // mobile_env.py:45
+    int dig[BT];
+#pragma unroll
+    for (int b = BT - 1; b >= 0; --b) {                         // least significant digit -> UAV B-1
+        dig[b] = 4;
+        if (b < B) {
+            const unsigned q = u32div(a, p.div_magic, p.div_shift);
+            dig[b] = (int)(a - q * n);
+            a = q;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+        if (i < B) {
+            // proposal (:221-253), branch-free: digits 0..3 step BS_STEP, 5..8 step 2*BS_STEP, in +x, -x, +y, -y;
+            // 4 (and anything else) stays.  Only the moved coordinate is bounds-checked, as in the reference.
+            const int di = dig[i];
+            const int dir = (di >= 5) ? di - 5 : di;
+            const int step = (di == 4 || di > 8) ? 0 : ((di >= 5) ? 2 * p.bs_step : p.bs_step);
+            const int ddx = (dir == 0) ? step : ((dir == 1) ? -step : 0);
+            const int ddy = (dir == 2) ? step : ((dir == 3) ? -step : 0);
+            const int nx = bsx[i] + ddx, ny = bsy[i] + ddy;
+            const int in_x = (ddx == 0) | ((nx > xMin) & (nx < xMax));
+            const int in_y = (ddy == 0) | ((ny > yMin) & (ny < yMax));
+            // collision (:256-263): PRE-move cell of i against the current cells of all j != i; integer form of
+            // norm <= min_dist, as a running minimum (one comparison, no chain of per-lane booleans)
+            int dmin = 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < BT; ++j) {
+                if (j != i && j < B) {
+                    const int dx = bsx[i] - bsx[j], dy = bsy[i] - bsy[j];
+                    const int d2 = dx * dx + dy * dy;
+                    dmin = d2 < dmin ? d2 : dmin;
+                }
+            }
+            const int go = in_x & in_y & (int)(dmin > p.min_bs_dist2);               // :265-266
+            bsx[i] += go * ddx;
+            bsy[i] += go * ddy;
+        }
+    }
 }
 
 // One next() of reference_point_group for one walker (ue_mobility.py:455-505): own step along the heading
@@ -218,11 +290,11 @@ __device__ __forceinline__ void group_finish(const KParams &p, const LeanCoef &C
 //     P*gain = k_pl * 10^(-f/10) * d^(-b/10)   for d > pl_dis   (b = 30: d^-3 = rsqrt(d^2)^3, no log: PLC)
 //            = k_0  * 10^(-f/10)               otherwise (loss = 0)
 // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
-// bs: this env's UAV cells in LDS ([2*B] ints).  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
+// bsx/bsy: this env's UAV cells, in registers.  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
 // Philox uniforms (one call -> two UAVs), replacing np.random.normal (channel.py:240).
 template <int BT, bool PLC, bool FAST>
 __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, const LeanCoef &C, long long e, uint32_t tick, int u, bool act,
-                                         long long iu, int ix, int iy, const int *bs, double pg[BT]) {
+                                         long long iu, int ix, int iy, const int (&bsx)[BT], const int (&bsy)[BT], double pg[BT]) {
     const int B = p.B;
 #pragma unroll
     for (int b2 = 0; b2 < BT; b2 += 2) {
@@ -251,8 +323,8 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
                 double g = 0.0;
                 if (b < B) {
                     const double f = (k == 0) ? f0 : f1;
-                    const double fx = H.gw * (double)(ix - bs[2 * b]);                // :221-222
-                    const double fy = H.gw * (double)(iy - bs[2 * b + 1]);
+                    const double fx = H.gw * (double)(ix - bsx[b]);                   // :221-222
+                    const double fy = H.gw * (double)(iy - bsy[b]);
                     const double d2 = fx * fx + fy * fy;                              // d^2, :223 (z ignored); exact
                     if (PLC) {
                         const double rinv = lm_rsqrt(d2);                             // d^-3 = (d2^-1/2)^3
@@ -407,6 +479,9 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 template <int BT, int MODE, bool PLC, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const KParams p) {
     __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
+    UAV_STAMP(ts0);                                   // wave start
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = p.U, B = p.B, Gr = p.Gr, EPW = p.epw;
@@ -431,13 +506,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     const bool bown = (MODE != MODE_WARMUP) && live && (ul < B);     // this lane owns UAV `ul`
     const bool gown = (has_mobility(MODE)) && live && (ul < Gr);     // this lane owns RPGM group `ul`
 
+    UAV_STAMP(ts1);                                   // first kernarg words arrived, lane bookkeeping done
     // ================= load phase: every global read of the launch, issued before any dependent work ======
-    int bx = 0, by = 0;
+    constexpr bool REG_MOVE = (BT <= 8);   // serial BS_move in registers; n_act^B <= 9^8 always fits 32 bits here
+    int bx = 0, by = 0;                    // the UAV this lane OWNS (store phase)
+    int bsx[BT], bsy[BT];                  // all UAV cells of this lane's env (rx_power reads them)
     long long act = 0, apw = 1;
-    if (bown) {
-        if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }  // mobile_env.py:119
-        else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
-        if (is_step(MODE)) { act = p.actions[e]; apw = p.act_pow[ul]; }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) { bsx[b] = 0; bsy[b] = 0; }
+    if (MODE != MODE_WARMUP) {
+        if (REG_MOVE) {
+            const int2 *cells = reinterpret_cast<const int2 *>(is_reset(MODE) ? p.bs_init : p.bs_xy + e * B * 2);
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+                if (b < B) { const int2 q = cells[b]; bsx[b] = q.x; bsy[b] = q.y; }   // mobile_env.py:119 on reset
+            if (is_step(MODE)) act = p.actions[e];
+        } else if (bown) {
+            if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }
+            else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
+            if (is_step(MODE)) { act = p.actions[e]; apw = p.act_pow[ul]; }
+        }
     }
     uint32_t tick = p.tick[e];
     int agg = 0, deagg = 0;
@@ -470,27 +558,48 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         prev_out = p.out_bits[e];
     }
 
+    UAV_DRAIN_VM();
+    UAV_STAMP(ts2);                                   // every load of the load phase has returned
     // ================= compute ===============================================================================
+#ifdef UAVENV_SKELETON   // diagnostic build (tools/ab_variants.sh): load phase + store phase only, to measure the fixed floor
+    double sum_cur = 0.0, cur = x + y + hu + ogx + ogy + ogfl + ogv + ogc + ogs + (double)(bx + by + bsx[0] + bsy[0] + bsx[BT - 1] + bsy[BT - 1] + (int)act + (int)apw + gid);
+    int n_outage = (int)(prev_out & 1ull) + serving + r0 + r1 + r2 + depth;
+    unsigned long long ob = prev_out;
+    tick += 1u;
+    (void)bs_row; (void)slot_mask; (void)n_ticks; (void)MAXC; (void)hu_inj; (void)C; (void)H;
+#else
     // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
     if (MODE != MODE_WARMUP) {
-        if (is_step(MODE)) {
-            int dig = 0;
-            if (bown) dig = action_digit(p, act, apw);
-            for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
-                const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
-                int nx, ny;
-                uav_propose(p, xi, yi, di, nx, ny);
-                // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
-                const int dx = xi - bx, dy = yi - by;
-                const bool near = bown && (ul != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
-                const bool collision = (__ballot(near) & slot_mask) != 0ull;
-                if (!collision && bown && ul == i) { bx = nx; by = ny; }
+        if (REG_MOVE) {
+            if (is_step(MODE)) bs_move_serial<BT>(p, (unsigned)act, bsx, bsy);
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+                if (ul == b) { bx = bsx[b]; by = bsy[b]; }             // the cell this lane writes back
+        } else {
+            // cooperative form for B > 8: one UAV per lane, sequential rounds, UAV cells staged in LDS
+            if (is_step(MODE)) {
+                int dig = 0;
+                if (bown) dig = action_digit(p, act, apw);
+                for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
+                    const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
+                    int nx, ny;
+                    uav_propose(p, xi, yi, di, nx, ny);
+                    // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
+                    const int dx = xi - bx, dy = yi - by;
+                    const bool near = bown && (ul != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
+                    const bool collision = (__ballot(near) & slot_mask) != 0ull;
+                    if (!collision && bown && ul == i) { bx = nx; by = ny; }
+                }
             }
+            if (bown) { bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < BT; ++b)
+                if (b < B) { bsx[b] = bs_row[2 * b]; bsy[b] = bs_row[2 * b + 1]; }
         }
-        if (bown) { bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by; }   // UAV cells staged in LDS for rx_power
-        __builtin_amdgcn_wave_barrier();
     }
 
+    UAV_STAMP(ts3);                                   // UAV move done
     // ---- mobility: n_ticks x next(self.mm); walker and group state stay in registers across ticks ----
     for (int it = 0; it < n_ticks; ++it) {
         if (has_mobility(MODE)) {
@@ -524,13 +633,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     }
     if (has_mobility(MODE)) { ix = (int)x; iy = (int)y; }                                // .astype(int), mobile_env.py:154-155
 
+    UAV_STAMP(ts4);                                   // mobility done
     // ---- channel update (one per reset / step; Philox time = the tick just executed) ------------------
     double sum_cur = 0.0, cur = 0.0;
     int n_outage = 0;
     unsigned long long ob = 0ull;
     if (MODE != MODE_WARMUP) {
         double pg[BT];
-        rx_power<BT, PLC, FAST>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bs_row, pg);
+        rx_power<BT, PLC, FAST>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, pg);
         const int best = argmax_pg<BT>(p, pg);
         const double bestS = sinr_db<BT>(p, H, C, pg, best);
         if (is_reset(MODE)) {
@@ -547,6 +657,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
         sum_cur = slot_sum(live ? cur : 0.0, ul, U);
     }
+#endif  // UAVENV_SKELETON
+    UAV_STAMP(ts5);                                   // channel update done
 
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
@@ -574,6 +686,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         if (MODE != MODE_WARMUP) p.out_bits[e] = ob;                                     // :116 / :173
         env_finish<MODE, FAST>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
+#ifdef UAVENV_STAMPS
+    UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
+    UAV_DRAIN_VM();
+    unsigned long long ts7 = 0;
+    UAV_STAMP(ts7);                                   // all stores acknowledged
+    if (p.dbg != nullptr && lane == 0) {
+        unsigned long long *d = p.dbg + ((long long)blockIdx.x * kWavesPerBlock + wave) * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = ts5; d[6] = ts6; d[7] = ts7;
+    }
+#endif
 }
 
 // ================================================================================================
@@ -622,6 +744,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             if (p.out.bs_xy) { p.out.bs_xy[(e * B + lane) * 2] = bx; p.out.bs_xy[(e * B + lane) * 2 + 1] = by; }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    int bsx[BT], bsy[BT];                  // UAV cells of this env, LDS row -> registers once (rx_power reads them)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        bsx[b] = 0; bsy[b] = 0;
+        if (MODE != MODE_WARMUP && b < B) { bsx[b] = s_bs[wave][2 * b]; bsy[b] = s_bs[wave][2 * b + 1]; }
     }
 
     int agg = 0, deagg = 0;
@@ -685,7 +813,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
             double pg[BT];
-            rx_power<BT, PLC, FAST>(p, H, C, e, tick, u, act, iu, ix, iy, s_bs[wave], pg);
+            rx_power<BT, PLC, FAST>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, pg);
             const int best = argmax_pg<BT>(p, pg);
             const double bestS = sinr_db<BT>(p, H, C, pg, best);
             if (is_reset(MODE)) {

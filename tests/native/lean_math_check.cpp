@@ -7,6 +7,7 @@
 #include <random>
 
 #include "../../drl_uav_cellularnet_amd/csrc/lean_math.h"
+#include "../../drl_uav_cellularnet_amd/csrc/intdiv.h"
 
 static double ulp_of(double ref) {
     int e;
@@ -63,5 +64,19 @@ int main() {
         [&](std::mt19937_64 &g) { return 2.0 * u01(g); }, n);
     run("rsqrt_dist2", [](double x) { return uavk::lm_rsqrt(x); }, [](long double x) { return 1.0L / std::sqrt(x); },
         [&](std::mt19937_64 &g) { return 25.0 * (double)(1 + g() % 2000000); }, n);
+    // exact multiply-shift division used for the action digits: every divisor 2..9, dense + random + edge dividends
+    {
+        std::mt19937_64 rng(7);
+        long long bad = 0, total = 0;
+        for (uint32_t d = 2; d <= 9; ++d) {
+            uint32_t magic, shift;
+            uavk::u32div_gen(d, &magic, &shift);
+            auto chk = [&](uint32_t a) { ++total; if (uavk::u32div(a, magic, shift) != a / d) ++bad; };
+            for (uint32_t a = 0; a < 3000000u; ++a) chk(a);
+            for (uint32_t a = 0xFFFFFFFFu; a > 0xFFFFFFFFu - 3000000u; --a) chk(a);
+            for (int i = 0; i < 3000000; ++i) chk((uint32_t)rng());
+        }
+        std::printf("u32div_mismatches %lld %lld 0\n", total, bad);
+    }
     return 0;
 }

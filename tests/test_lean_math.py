@@ -16,7 +16,7 @@ def test_lean_math_accuracy(tmp_path):
     rows = {}
     for line in subprocess.check_output([exe], text=True).splitlines():
         name, n, worst, mean = line.split()
-        rows[name] = (int(n), float(worst), float(mean))
+        rows[name] = (int(n), float(worst), float(mean))   # (u32div row: total, mismatches, 0)
     for name in ("log_one_minus_u", "log_sinr_ratio", "log_near_one"):
         n, worst, mean = rows[name]
         assert n == 2000000
@@ -31,3 +31,5 @@ def test_lean_math_accuracy(tmp_path):
         n, worst, mean = rows[name]
         assert worst < 2.0 and mean < 0.4, "%s: %.3f ulp" % (name, worst)
     assert "rsqrt_dist2" in rows
+    total, bad, _ = rows["u32div_mismatches"]          # csrc/intdiv.h: exact a / d for d = 2..9 (action digits)
+    assert total == 8 * 9000000 and bad == 0
