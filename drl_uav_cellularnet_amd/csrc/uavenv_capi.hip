@@ -286,7 +286,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     const dim3 blk(64 * kWavesPerBlock);
     if (MODE == MODE_WARMUP) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
-        const bool fast = !p.inj_theta && !p.inj_group;
+        const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4
         if (h->packed) {
             if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, p);
             else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, p);
@@ -297,7 +297,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
         return UAVENV_OK;
     }
     constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
-    const bool fast = call_is_fast(p);
+    const bool fast = call_is_fast(p) && (p.B == h->bt);   // FAST kernels are compiled for B == BT exactly
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
         if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true>), dim3(grid), blk, 0, s, p);          \

@@ -51,6 +51,11 @@ __host__ __device__ constexpr bool has_mobility(int m) { return m == MODE_WARMUP
 // float64 copies (what BatchedMobiEnv.step does): every optional-pointer test folds away at compile time.
 // Why it matters: each runtime test was a scalar kernarg load + s_waitcnt lgkmcnt(0) + branch; the r01_v3
 // profile has 59 such drains per wave = 47 % of the wave cycles (profiles/r01_v3_packed_sq_counters.txt).
+// FAST additionally means B == BT (host: launch_env), so every `b < B` guard of the unrolled per-UAV loops folds at
+// compile time.  Left as run-time tests they were uniform branches, and hipcc parked hoisted kernarg loads in the
+// little blocks between them, each with its own s_waitcnt (stamps: ~9 serial scalar round trips in the UAV-move phase).
+template <int BT, bool FAST>
+__device__ __forceinline__ int uav_count(int runtime_b) { return FAST ? BT : runtime_b; }
 #define UAV_INJ(ptr) (!FAST && (ptr) != nullptr)     /* injected draws present            */
 #define UAV_OUT(ptr) (FAST || (ptr) != nullptr)      /* standard output requested         */
 #define UAV_OUT64(ptr) (!FAST && (ptr) != nullptr)   /* optional float64 copy requested   */
@@ -110,6 +115,29 @@ struct InitParams {
 #define UAV_STAMP(var) do { } while (0)
 #define UAV_DRAIN_VM() do { } while (0)
 #endif
+
+// Kernarg warm-up.  hipcc loads kernarg fields lazily, one scalar-load batch per block that first uses them, and the
+// phase stamps (gpurun_out/stamps_*.log) show a cold kernarg fetch costing ~1900 ticks (~1 us):
+// the kernarg block is rewritten for every launch, so the first touch of each 64-byte line misses every cache.
+// Forcing HOST kernargs (HIP_FORCE_DEV_KERNARG=0) makes the launch 46 % slower, i.e. this latency is first-order.
+// Here every line of the block is touched once at kernel entry by independent scalar loads (one round trip for all
+// of them); the later lazy loads then hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#ifndef UAVENV_NO_KERNARG_WARM
+    typedef const __attribute__((address_space(4))) unsigned int *kptr_t;
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    // All loads are consumed by ONE asm statement, so they are issued back to back and waited for once.  (One asm per
+    // load made hipcc emit load, s_waitcnt, load, s_waitcnt ...: ten serial round trips instead of one.)
+    constexpr int LINES = (BYTES + 63) / 64;
+    static_assert(LINES <= 16, "kernarg block larger than the 16 lines this warm-up touches");
+    unsigned int v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (i < LINES) ? ka[i * 16] : 0u;
+    asm volatile("" ::"s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]),
+                 "s"(v[9]), "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+#endif
+}
 
 // ================================================================================================
 // shared device helpers (both env kernels run exactly this arithmetic)
@@ -180,9 +208,9 @@ __device__ __forceinline__ void uav_propose(const KParams &p, int xi, int yi, in
 // sequential round, LDS staging + barrier) took 21 % of a wavefront's lifetime, more than twice the mobility tick.
 // Semantics as ue_mobility.py:191-271: UAV i proposes from digit i (most significant digit -> UAV 0, :310-336), the
 // collision test uses i's PRE-move cell against the already-updated cells of j < i and the old cells of j > i.
-template <int BT>
+template <int BT, bool FAST>
 __device__ __forceinline__ void bs_move_serial(const KParams &p, unsigned a, int (&bsx)[BT], int (&bsy)[BT]) {
-    const int B = p.B;
+    const int B = uav_count<BT, FAST>(p.B);
     const unsigned n = (unsigned)p.n_act;
     const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;      // mobile_env.py:45
     int dig[BT];
@@ -295,7 +323,7 @@ __device__ __forceinline__ void group_finish(const KParams &p, const LeanCoef &C
 template <int BT, bool PLC, bool FAST>
 __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, const LeanCoef &C, long long e, uint32_t tick, int u, bool act,
                                          long long iu, int ix, int iy, const int (&bsx)[BT], const int (&bsy)[BT], double pg[BT]) {
-    const int B = p.B;
+    const int B = uav_count<BT, FAST>(p.B);
 #pragma unroll
     for (int b2 = 0; b2 < BT; b2 += 2) {
         double f0 = 0.0, f1 = 0.0;
@@ -342,24 +370,26 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
 
 // Best UAV: SINR_b = pg_b / (noise + sum_{j != b} pg_j) is strictly increasing in pg_b (the total is fixed),
 // so np.argmax over the dB values (channel.py:141) == first maximum of pg.
-template <int BT>
+template <int BT, bool FAST>
 __device__ __forceinline__ int argmax_pg(const KParams &p, const double pg[BT]) {
+    const int B = uav_count<BT, FAST>(p.B);
     int best = 0;
     double bp = pg[0];
 #pragma unroll
     for (int b = 1; b < BT; ++b)
-        if (b < p.B && pg[b] > bp) { bp = pg[b]; best = b; }
+        if (b < B && pg[b] > bp) { bp = pg[b]; best = b; }
     return best;
 }
 
 // 10*log10(S/(N+I)) for UAV x (channel.py:259-268); interference = the OTHER UAVs summed in index order,
 // never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
-template <int BT>
+template <int BT, bool FAST>
 __device__ __forceinline__ double sinr_db(const KParams &p, const HotConst &H, const LeanCoef &C, const double pg[BT], int x) {
+    const int B = uav_count<BT, FAST>(p.B);
     double interf = 0.0, px = 0.0;
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-        interf += (j != x && j < p.B) ? pg[j] : 0.0;
+        interf += (j != x && j < B) ? pg[j] : 0.0;
         px = (j == x) ? pg[j] : px;
     }
     return H.db_per_ln * lm_logc(px / (H.noise + interf), C);   // 10*log10(x) = (10/ln 10) * ln x
@@ -482,9 +512,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
+    kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int U = p.U, B = p.B, Gr = p.Gr, EPW = p.epw;
+    const int U = p.U, B = uav_count<BT, FAST>(p.B), Gr = p.Gr, EPW = p.epw;
     int slot = 0;
     for (int s = 1; s < EPW; ++s) slot += (lane >= s * U) ? 1 : 0;
     const int base = slot * U;   // first lane of my slot
@@ -571,7 +602,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
     if (MODE != MODE_WARMUP) {
         if (REG_MOVE) {
-            if (is_step(MODE)) bs_move_serial<BT>(p, (unsigned)act, bsx, bsy);
+            if (is_step(MODE)) bs_move_serial<BT, FAST>(p, (unsigned)act, bsx, bsy);
 #pragma unroll
             for (int b = 0; b < BT; ++b)
                 if (ul == b) { bx = bsx[b]; by = bsy[b]; }             // the cell this lane writes back
@@ -641,8 +672,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     if (MODE != MODE_WARMUP) {
         double pg[BT];
         rx_power<BT, PLC, FAST>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, pg);
-        const int best = argmax_pg<BT>(p, pg);
-        const double bestS = sinr_db<BT>(p, H, C, pg, best);
+        const int best = argmax_pg<BT, FAST>(p, pg);
+        const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
         if (is_reset(MODE)) {
             // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
             cur = bestS;
@@ -650,7 +681,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
             r0 = best;                                                                   // bestBS_buf = [current_BS]
         } else {
             // UpdateDroneNet, DL part (channel.py:141-174)
-            cur = sinr_db<BT>(p, H, C, pg, serving);       // serving UAV BEFORE any handover (:145-146)
+            cur = sinr_db<BT, FAST>(p, H, C, pg, serving);       // serving UAV BEFORE any handover (:145-146)
             fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
         }
         ob = (__ballot(live && (cur <= H.out_thr)) & slot_mask) >> base;               // :116 / :170
@@ -706,6 +737,7 @@ template <int BT, int MODE, bool PLC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(const KParams p) {
     constexpr bool FAST = false;  // U > 64: per-wave work is large, the checked path is kept
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
+    kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
@@ -814,8 +846,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
             double pg[BT];
             rx_power<BT, PLC, FAST>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, pg);
-            const int best = argmax_pg<BT>(p, pg);
-            const double bestS = sinr_db<BT>(p, H, C, pg, best);
+            const int best = argmax_pg<BT, FAST>(p, pg);
+            const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
             if (is_reset(MODE)) {
                 const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
                 if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
@@ -833,7 +865,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                     serving = p.serving[iu];
                     r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
                 }
-                const double cur = sinr_db<BT>(p, H, C, pg, serving);
+                const double cur = sinr_db<BT, FAST>(p, H, C, pg, serving);
                 fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
                 const unsigned long long ob = __ballot(act && (cur <= H.out_thr));
                 const unsigned long long prev = p.out_bits[e * p.W64 + pass];
