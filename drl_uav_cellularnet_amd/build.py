@@ -11,8 +11,9 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 SRC = os.path.join(PKG_DIR, "csrc", "uavenv_capi.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "uavenv_kernels.h"), os.path.join(PKG_DIR, "csrc", "philox.h"),
-        os.path.join(ROOT, "include", "uavenv.h")]
+DEPS = [SRC] + [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "philox.h", "lean_math.h", "intdiv.h",
+                                                            "state_layout.h")] + [
+    os.path.join(ROOT, "include", "uavenv.h")]
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libuavenv.so")
 ARCH = "gfx950"
@@ -36,8 +37,10 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave launch (the packed env
+    # kernel starts its global loads from them while the parameter struct is still being fetched)
     cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16", *extra_flags, "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -135,20 +135,18 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     uavenv *h = new (std::nothrow) uavenv();
     if (!h) return fail(UAVENV_E_NOMEM, "create: host allocation failed");
     h->cfg = *cfg; h->N = n_envs; h->device = device; h->seed = seed; h->env_id_base = env_id_base;
-    const size_t N = (size_t)n_envs, U = (size_t)cfg->n_ue, B = (size_t)cfg->n_bs, Gr = (size_t)cfg->n_groups;
+    const size_t U = (size_t)cfg->n_ue, B = (size_t)cfg->n_bs;
     const size_t W64 = (U + 63) / 64;
     h->bt = B <= 4 ? 4 : B <= 8 ? 8 : B <= 16 ? 16 : 32;
 
+    // one layout definition shared with the device code (state_layout.h)
+    const StateOffsets SO = compute_layout(n_envs, cfg->n_ue, cfg->n_bs, cfg->n_groups);
     UavEnvStateLayout &L = h->lay;
-    size_t off = 0;
-    auto put = [&](size_t &field, size_t bytes) { field = off; off = align_up(off + bytes, 256); };
-    put(L.ue_x, N * U * 8); put(L.ue_y, N * U * 8); put(L.ue_hu, N * U * 8);
-    put(L.g_x, N * Gr * 8); put(L.g_y, N * Gr * 8); put(L.g_fl, N * Gr * 8);
-    put(L.g_v, N * Gr * 8); put(L.g_cos, N * Gr * 8); put(L.g_sin, N * Gr * 8);
-    put(L.agg, N * 4); put(L.deagg, N * 4); put(L.tick, N * 4);
-    put(L.bs_xy, N * B * 2 * 4); put(L.serving, N * U); put(L.fifo, N * 3 * U); put(L.fifo_depth, N * 4);
-    put(L.out_bits, N * W64 * 8); put(L.step_n, N * 4); put(L.ue_xy, N * U * 2 * 2);
-    L.total_bytes = off;
+    L.total_bytes = SO.total;
+    L.ue_x = SO.ue_x; L.ue_y = SO.ue_y; L.ue_hu = SO.ue_hu;
+    L.g_x = SO.g_x; L.g_y = SO.g_y; L.g_fl = SO.g_fl; L.g_v = SO.g_v; L.g_cos = SO.g_cos; L.g_sin = SO.g_sin;
+    L.agg = SO.agg; L.deagg = SO.deagg; L.tick = SO.tick; L.bs_xy = SO.bs_xy; L.serving = SO.serving; L.fifo = SO.fifo;
+    L.fifo_depth = SO.fifo_depth; L.out_bits = SO.out_bits; L.step_n = SO.step_n; L.ue_xy = SO.ue_xy;
 
     hipError_t e = hipMalloc((void **)&h->blob, L.total_bytes);
     if (e != hipSuccess) { delete h; return fail(UAVENV_E_NOMEM, std::string("create: hipMalloc state: ") + hipGetErrorString(e)); }
@@ -284,12 +282,15 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     const long long waves = (p.N + p.epw - 1) / p.epw;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
+    // leading scalar arguments of the packed kernels: delivered in SGPRs at wave launch (kernarg preload), see
+    // env_kernel_packed.  The slab base replaces the 19 per-field pointers (state_layout.h).
+#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, p
     if (MODE == MODE_WARMUP) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
         const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4
         if (h->packed) {
-            if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, p);
-            else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, p);
+            if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, PK_ARGS);
+            else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, PK_ARGS);
         } else {
             hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true>), dim3(grid), blk, 0, s, p);
         }
@@ -300,8 +301,8 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     const bool fast = call_is_fast(p) && (p.B == h->bt);   // FAST kernels are compiled for B == BT exactly
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
-        if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true>), dim3(grid), blk, 0, s, p);          \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false>), dim3(grid), blk, 0, s, p);              \
+        if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true>), dim3(grid), blk, 0, s, PK_ARGS);          \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false>), dim3(grid), blk, 0, s, PK_ARGS);              \
     } while (0)
 #define UAVENV_LAUNCH(BT_)                                                                                       \
     do {                                                                                                         \
@@ -320,6 +321,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     }
 #undef UAVENV_LAUNCH
 #undef UAVENV_LAUNCH_PK
+#undef PK_ARGS
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

@@ -25,6 +25,7 @@
 #include "intdiv.h"
 #include "lean_math.h"
 #include "philox.h"
+#include "state_layout.h"
 
 namespace uavk {
 
@@ -100,6 +101,35 @@ struct InitParams {
     unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy; const int32_t *bs_init;
     const double *u_x, *u_y, *u_th, *u_g;
 };
+
+// Typed pointers to the state fields of one handle.  The packed kernel builds them from the slab base + the shared
+// layout function (scalar arithmetic on preloaded arguments); the multi-pass kernel copies them from KParams.
+struct StatePtrs {
+    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
+    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
+    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
+};
+__device__ __forceinline__ StatePtrs state_from_blob(char *b, long long N, int U, int B, int Gr) {
+    const StateOffsets L = compute_layout(N, U, B, Gr);
+    StatePtrs s;
+    s.ue_x = (double *)(b + L.ue_x); s.ue_y = (double *)(b + L.ue_y); s.ue_hu = (double *)(b + L.ue_hu);
+    s.g_x = (double *)(b + L.g_x); s.g_y = (double *)(b + L.g_y); s.g_fl = (double *)(b + L.g_fl);
+    s.g_v = (double *)(b + L.g_v); s.g_cos = (double *)(b + L.g_cos); s.g_sin = (double *)(b + L.g_sin);
+    s.agg = (int32_t *)(b + L.agg); s.deagg = (int32_t *)(b + L.deagg); s.tick = (uint32_t *)(b + L.tick);
+    s.bs_xy = (int32_t *)(b + L.bs_xy); s.serving = (int8_t *)(b + L.serving); s.fifo = (int8_t *)(b + L.fifo);
+    s.fifo_depth = (int32_t *)(b + L.fifo_depth); s.out_bits = (unsigned long long *)(b + L.out_bits);
+    s.step_n = (int32_t *)(b + L.step_n); s.ue_xy = (int16_t *)(b + L.ue_xy);
+    return s;
+}
+
+__device__ __forceinline__ StatePtrs state_from_params(const KParams &p) {
+    StatePtrs s;
+    s.ue_x = p.ue_x; s.ue_y = p.ue_y; s.ue_hu = p.ue_hu; s.g_x = p.g_x; s.g_y = p.g_y; s.g_fl = p.g_fl; s.g_v = p.g_v;
+    s.g_cos = p.g_cos; s.g_sin = p.g_sin; s.agg = p.agg; s.deagg = p.deagg; s.tick = p.tick; s.bs_xy = p.bs_xy;
+    s.serving = p.serving; s.fifo = p.fifo; s.fifo_depth = p.fifo_depth; s.out_bits = p.out_bits; s.step_n = p.step_n;
+    s.ue_xy = p.ue_xy;
+    return s;
+}
 
 // In-kernel phase stamps (diagnostic build -DUAVENV_STAMPS only; MI355X guide, "In-kernel stamps"): one asm
 // statement per stamp with its own lgkmcnt(0), scheduling barriers around it.  Values go to p.dbg, never to outputs.
@@ -408,13 +438,13 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
 template <int MODE, bool FAST>
-__device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32_t tick, int agg, int deagg, int depth,
+__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, long long e, uint32_t tick, int agg, int deagg, int depth,
                                            int step_n, double sum_cur, int n_outage) {
-    p.tick[e] = tick;
-    if (has_mobility(MODE)) { p.agg[e] = agg; p.deagg[e] = deagg; }
+    st.tick[e] = tick;
+    if (has_mobility(MODE)) { st.agg[e] = agg; st.deagg[e] = deagg; }
     if (is_reset(MODE)) {
-        p.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
-        p.step_n[e] = 0;                                      // mobile_env.py:146
+        st.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
+        st.step_n[e] = 0;                                      // mobile_env.py:146
         const double mean = sum_cur / (double)p.U;
         if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = 0;
         if (UAV_OUT(p.out.reward)) p.out.reward[e] = 0.f;
@@ -425,14 +455,14 @@ __device__ __forceinline__ void env_finish(const KParams &p, long long e, uint32
         if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
     }
     if (is_step(MODE)) {
-        if (depth < 3) p.fifo_depth[e] = depth + 1;
+        if (depth < 3) st.fifo_depth[e] = depth + 1;
         const double mean = sum_cur / (double)p.U;            // channel.py:216
         const double r0 = mean / 20.0;                        // mobile_env.py:165
         const double r1 = -1.0 * (double)n_outage / (double)p.U;  // mobile_env.py:167
         double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
-        p.step_n[e] = step_n;
+        st.step_n[e] = step_n;
         if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = step_n;
         if (UAV_OUT(p.out.done)) p.out.done[e] = (uint8_t)(step_n >= p.max_step);
         if (UAV_OUT(p.out.reward)) p.out.reward[e] = (float)reward;
@@ -507,28 +537,30 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // BT: compile-time bound on B.  PLC: pl_b == 30 (channel.py:47) => d^-3 by sqrt.
 // ================================================================================================
 template <int BT, int MODE, bool PLC, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const KParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
+                                                                              const int8_t *gid_of_u, long long N, int U, int EPW,
+                                                                              int Gr, int B_rt, const KParams p) {
+    // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
+    // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
+    // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
     __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
-    kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int U = p.U, B = uav_count<BT, FAST>(p.B), Gr = p.Gr, EPW = p.epw;
+    const int B = uav_count<BT, FAST>(B_rt);
+    const StatePtrs st = state_from_blob(blob, N, U, B, Gr);
     int slot = 0;
     for (int s = 1; s < EPW; ++s) slot += (lane >= s * U) ? 1 : 0;
     const int base = slot * U;   // first lane of my slot
     const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
     long long e = ((long long)blockIdx.x * kWavesPerBlock + wave) * EPW + slot;
-    bool live = (lane < EPW * U) && (e < p.N);
+    bool live = (lane < EPW * U) && (e < N);
     if (is_reset(MODE)) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
     if (__ballot(live) == 0ull) return;
-    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
-    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
     const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
-    const double MAXC = H.maxc;
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
@@ -547,33 +579,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     for (int b = 0; b < BT; ++b) { bsx[b] = 0; bsy[b] = 0; }
     if (MODE != MODE_WARMUP) {
         if (REG_MOVE) {
-            const int2 *cells = reinterpret_cast<const int2 *>(is_reset(MODE) ? p.bs_init : p.bs_xy + e * B * 2);
+            const int2 *cells = reinterpret_cast<const int2 *>(is_reset(MODE) ? p.bs_init : st.bs_xy + e * B * 2);
 #pragma unroll
             for (int b = 0; b < BT; ++b)
                 if (b < B) { const int2 q = cells[b]; bsx[b] = q.x; bsy[b] = q.y; }   // mobile_env.py:119 on reset
-            if (is_step(MODE)) act = p.actions[e];
+            if (is_step(MODE)) act = actions[e];
         } else if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }
-            else { bx = p.bs_xy[(e * B + ul) * 2]; by = p.bs_xy[(e * B + ul) * 2 + 1]; }
-            if (is_step(MODE)) { act = p.actions[e]; apw = p.act_pow[ul]; }
+            else { bx = st.bs_xy[(e * B + ul) * 2]; by = st.bs_xy[(e * B + ul) * 2 + 1]; }
+            if (is_step(MODE)) { act = actions[e]; apw = p.act_pow[ul]; }
         }
     }
-    uint32_t tick = p.tick[e];
+    uint32_t tick = st.tick[e];
     int agg = 0, deagg = 0;
-    if (has_mobility(MODE)) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    if (has_mobility(MODE)) { agg = st.agg[e]; deagg = st.deagg[e]; }
     int depth = 0, step_n = 0;
-    if (is_step(MODE)) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    if (is_step(MODE)) { depth = st.fifo_depth[e]; step_n = st.step_n[e]; }
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
-        ogx = p.g_x[e * Gr + ul]; ogy = p.g_y[e * Gr + ul]; ogfl = p.g_fl[e * Gr + ul];
-        ogv = p.g_v[e * Gr + ul]; ogc = p.g_cos[e * Gr + ul]; ogs = p.g_sin[e * Gr + ul];
+        ogx = st.g_x[e * Gr + ul]; ogy = st.g_y[e * Gr + ul]; ogfl = st.g_fl[e * Gr + ul];
+        ogv = st.g_v[e * Gr + ul]; ogc = st.g_cos[e * Gr + ul]; ogs = st.g_sin[e * Gr + ul];
     }
     double x = 0, y = 0, hu = 0, hu_inj = 0;
     int ix = 0, iy = 0, gid = 0;
     if (has_mobility(MODE)) {
-        gid = p.gid_of_u[u];                                      // table padded to >= 64 entries: dead lanes have u < 64
+        gid = gid_of_u[u];                                         // table padded to >= 64 entries: dead lanes have u < 64
         if (live) {
-            x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu];
+            x = st.ue_x[iu]; y = st.ue_y[iu]; hu = st.ue_hu[iu];
             if (UAV_INJ(p.inj_theta)) hu_inj = p.inj_theta[iu];   // injected draws cover exactly one tick
         }
     } else if (live) {                                            // mobile_env.py:202-203 (read_trace)
@@ -583,12 +615,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
     unsigned long long prev_out = 0ull;
     if (is_step(MODE)) {
         if (live) {
-            serving = p.serving[iu];
-            r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
+            serving = st.serving[iu];
+            r0 = st.fifo[(e * 3 + 0) * U + u]; r1 = st.fifo[(e * 3 + 1) * U + u]; r2 = st.fifo[(e * 3 + 2) * U + u];
         }
-        prev_out = p.out_bits[e];
+        prev_out = st.out_bits[e];
     }
 
+    // Only now touch the parameter struct: its (cold) kernarg fetch overlaps the global loads issued above.
+    __builtin_amdgcn_sched_barrier(0);
+    kernarg_warm<(int)sizeof(KParams)>();
+    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
+    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
+    const double MAXC = H.maxc;
     UAV_DRAIN_VM();
     UAV_STAMP(ts2);                                   // every load of the load phase has returned
     // ================= compute ===============================================================================
@@ -693,12 +731,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
 
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
-        if (has_mobility(MODE)) { p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu; }
-        p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+        if (has_mobility(MODE)) { st.ue_x[iu] = x; st.ue_y[iu] = y; st.ue_hu[iu] = hu; }
+        st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
         if (MODE != MODE_WARMUP) {
-            p.serving[iu] = (int8_t)serving;
-            p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-            if (!is_reset(MODE)) { p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
+            st.serving[iu] = (int8_t)serving;
+            st.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
+            if (!is_reset(MODE)) { st.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; st.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
             if (UAV_OUT(p.out.ue_xy)) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
             if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
             if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
@@ -706,16 +744,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
         }
     }
     if (gown) {
-        p.g_x[e * Gr + ul] = ogx; p.g_y[e * Gr + ul] = ogy; p.g_fl[e * Gr + ul] = ogfl;
-        p.g_v[e * Gr + ul] = ogv; p.g_cos[e * Gr + ul] = ogc; p.g_sin[e * Gr + ul] = ogs;
+        st.g_x[e * Gr + ul] = ogx; st.g_y[e * Gr + ul] = ogy; st.g_fl[e * Gr + ul] = ogfl;
+        st.g_v[e * Gr + ul] = ogv; st.g_cos[e * Gr + ul] = ogc; st.g_sin[e * Gr + ul] = ogs;
     }
     if (bown) {
-        p.bs_xy[(e * B + ul) * 2] = bx; p.bs_xy[(e * B + ul) * 2 + 1] = by;
+        st.bs_xy[(e * B + ul) * 2] = bx; st.bs_xy[(e * B + ul) * 2 + 1] = by;
         if (UAV_OUT(p.out.bs_xy)) { p.out.bs_xy[(e * B + ul) * 2] = bx; p.out.bs_xy[(e * B + ul) * 2 + 1] = by; }
     }
     if (head) {
-        if (MODE != MODE_WARMUP) p.out_bits[e] = ob;                                     // :116 / :173
-        env_finish<MODE, FAST>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        if (MODE != MODE_WARMUP) st.out_bits[e] = ob;                                     // :116 / :173
+        env_finish<MODE, FAST>(p, st, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -735,6 +773,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(const K
 // ================================================================================================
 template <int BT, int MODE, bool PLC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(const KParams p) {
+    const StatePtrs st = state_from_params(p);
     constexpr bool FAST = false;  // U > 64: per-wave work is large, the checked path is kept
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
     kernarg_warm<(int)sizeof(KParams)>();
@@ -756,7 +795,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         int bx = 0, by = 0, dig = 0;
         if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }
-            else { bx = p.bs_xy[(e * B + lane) * 2]; by = p.bs_xy[(e * B + lane) * 2 + 1]; }
+            else { bx = st.bs_xy[(e * B + lane) * 2]; by = st.bs_xy[(e * B + lane) * 2 + 1]; }
         }
         if (is_step(MODE)) {
             if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane]);
@@ -771,7 +810,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             }
         }
         if (bown) {
-            p.bs_xy[(e * B + lane) * 2] = bx; p.bs_xy[(e * B + lane) * 2 + 1] = by;
+            st.bs_xy[(e * B + lane) * 2] = bx; st.bs_xy[(e * B + lane) * 2 + 1] = by;
             s_bs[wave][2 * lane] = bx; s_bs[wave][2 * lane + 1] = by;
             if (p.out.bs_xy) { p.out.bs_xy[(e * B + lane) * 2] = bx; p.out.bs_xy[(e * B + lane) * 2 + 1] = by; }
         }
@@ -785,10 +824,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     }
 
     int agg = 0, deagg = 0;
-    uint32_t tick = p.tick[e];
-    if (has_mobility(MODE)) { agg = p.agg[e]; deagg = p.deagg[e]; }
+    uint32_t tick = st.tick[e];
+    if (has_mobility(MODE)) { agg = st.agg[e]; deagg = st.deagg[e]; }
     int depth = 0, step_n = 0;
-    if (is_step(MODE)) { depth = p.fifo_depth[e]; step_n = p.step_n[e]; }
+    if (is_step(MODE)) { depth = st.fifo_depth[e]; step_n = st.step_n[e]; }
     const bool gown = lane < Gr;
 
     double sum_cur = 0.0;
@@ -799,8 +838,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         const bool aggregating = agg != 0;
         if (has_mobility(MODE)) {
             if (gown) {
-                ogx = p.g_x[e * Gr + lane]; ogy = p.g_y[e * Gr + lane]; ogfl = p.g_fl[e * Gr + lane];
-                ogv = p.g_v[e * Gr + lane]; ogc = p.g_cos[e * Gr + lane]; ogs = p.g_sin[e * Gr + lane];
+                ogx = st.g_x[e * Gr + lane]; ogy = st.g_y[e * Gr + lane]; ogfl = st.g_fl[e * Gr + lane];
+                ogv = st.g_v[e * Gr + lane]; ogc = st.g_cos[e * Gr + lane]; ogs = st.g_sin[e * Gr + lane];
                 ogx = ogx + ogv * ogc;
                 ogy = ogy + ogv * ogs;
             }
@@ -818,7 +857,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
                 const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
                 double x = 0, y = 0, hu = 0;
-                if (act) { x = p.ue_x[iu]; y = p.ue_y[iu]; hu = p.ue_hu[iu]; }
+                if (act) { x = st.ue_x[iu]; y = st.ue_y[iu]; hu = st.ue_hu[iu]; }
                 bool c[4];
                 walker_move(H, C, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
                 c[0] = c[0] && act; c[1] = c[1] && act; c[2] = c[2] && act; c[3] = c[3] && act;
@@ -834,12 +873,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                 else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
                 ix = (int)x; iy = (int)y;
                 if (act) {
-                    p.ue_x[iu] = x; p.ue_y[iu] = y; p.ue_hu[iu] = hu;
-                    p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+                    st.ue_x[iu] = x; st.ue_y[iu] = y; st.ue_hu[iu] = hu;
+                    st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
                 }
             } else if (act) {
                 ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
-                p.ue_xy[2 * iu] = (int16_t)ix; p.ue_xy[2 * iu + 1] = (int16_t)iy;
+                st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
             }
             if (MODE == MODE_WARMUP) continue;
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
@@ -850,10 +889,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
             if (is_reset(MODE)) {
                 const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
-                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
+                if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
-                    p.serving[iu] = (int8_t)best;
-                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
+                    st.serving[iu] = (int8_t)best;
+                    st.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
                     if (p.out.serving) p.out.serving[iu] = (int8_t)best;
                     if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
                     if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
@@ -862,20 +901,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             } else {
                 int serving = 0, r0 = 0, r1 = 0, r2 = 0;
                 if (act) {
-                    serving = p.serving[iu];
-                    r0 = p.fifo[(e * 3 + 0) * U + u]; r1 = p.fifo[(e * 3 + 1) * U + u]; r2 = p.fifo[(e * 3 + 2) * U + u];
+                    serving = st.serving[iu];
+                    r0 = st.fifo[(e * 3 + 0) * U + u]; r1 = st.fifo[(e * 3 + 1) * U + u]; r2 = st.fifo[(e * 3 + 2) * U + u];
                 }
                 const double cur = sinr_db<BT, FAST>(p, H, C, pg, serving);
                 fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
                 const unsigned long long ob = __ballot(act && (cur <= H.out_thr));
-                const unsigned long long prev = p.out_bits[e * p.W64 + pass];
+                const unsigned long long prev = st.out_bits[e * p.W64 + pass];
                 n_outage += __popcll(ob & ~prev);
-                if (lane == 0) p.out_bits[e * p.W64 + pass] = ob;
+                if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
-                    p.serving[iu] = (int8_t)serving;
-                    p.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-                    p.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
-                    p.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
+                    st.serving[iu] = (int8_t)serving;
+                    st.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
+                    st.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
+                    st.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
                     if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
                     if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
                     if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
@@ -887,15 +926,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         if (has_mobility(MODE)) {
             if (gown) {
                 group_finish<FAST>(p, C, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
-                p.g_x[e * Gr + lane] = ogx; p.g_y[e * Gr + lane] = ogy; p.g_fl[e * Gr + lane] = ogfl;
-                p.g_v[e * Gr + lane] = ogv; p.g_cos[e * Gr + lane] = ogc; p.g_sin[e * Gr + lane] = ogs;
+                st.g_x[e * Gr + lane] = ogx; st.g_y[e * Gr + lane] = ogy; st.g_fl[e * Gr + lane] = ogfl;
+                st.g_v[e * Gr + lane] = ogv; st.g_cos[e * Gr + lane] = ogc; st.g_sin[e * Gr + lane] = ogs;
             }
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }
         }
         tick += 1u;
     }
-    if (lane == 0) env_finish<MODE, FAST>(p, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (lane == 0) env_finish<MODE, FAST>(p, st, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
 // ================================================================================================

@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   mkdir -p $OUT
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}; flags=${v#*:}
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wno-unused-function $flags -o $OUT/libuavenv_$name.so $SRC &
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 $flags -o $OUT/libuavenv_$name.so $SRC &
   done
   wait; ls -la $OUT
 else
