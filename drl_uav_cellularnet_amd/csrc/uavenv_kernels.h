@@ -211,6 +211,19 @@ __device__ __forceinline__ void philox_u2(const KParams &p, uint32_t env, uint32
     u1 = u53(r.z, r.w);
 }
 
+// Per-UE draw block of a tick (the oracle defines the same stream, oracle/uavenv_oracle.c):
+//   call p of walker u:  q_p = Philox(ctr = (env, tick, u*HB + p, DOM_FADING)),  HB = ceil(B/2)
+//   q_p.x, q_p.y -> 53-bit uniform of the Box-Muller radius;  q_p.z * 2^-32 -> angle fraction;  q_p.w -> spare
+//   heading uniform drawn this tick = u53(q_0.w, q_1.w)  (HB >= 2)   or   q_0.w * 2^-32  (HB == 1)
+// Two Philox calls per UE and tick instead of three: the quarter-rate 32x32->64 multiplies of Philox were ~17 % of
+// the step kernel's issue cycles.
+__device__ __forceinline__ U4 philox_raw(const KParams &p, uint32_t env, uint32_t tick, uint32_t idx, uint32_t dom) {
+    return philox4x32_10(p.env_id_base + env, tick, idx, dom, p.key0, p.key1);
+}
+__device__ __forceinline__ double heading_from(const U4 &q0, const U4 &q1, int HB) {
+    return (HB >= 2) ? u53(q0.w, q1.w) : (double)q0.w * (1.0 / 4294967296.0);
+}
+
 // Digit of UAV b in the joint action: Decimal_to_Base_N (ue_mobility.py:310-336), most significant digit ->
 // UAV 0.  One division per UAV lane, all UAVs in parallel (pw = n_act^(B-1-b)).
 __device__ __forceinline__ int action_digit(const KParams &p, long long a, long long pw) {
@@ -350,9 +363,11 @@ __device__ __forceinline__ void group_finish(const KParams &p, const LeanCoef &C
 // k_pl = P*10^((ant-a-eq)/10), k_0 = P*10^((ant-eq)/10) are folded on the host (float64 pow).
 // bsx/bsy: this env's UAV cells, in registers.  f ~ N(mean, sd) per (UE, UAV): injected, or Box-Muller on
 // Philox uniforms (one call -> two UAVs), replacing np.random.normal (channel.py:240).
-template <int BT, bool PLC, bool FAST>
+template <int BT, bool PLC, bool FAST, bool PRE>
 __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, const LeanCoef &C, long long e, uint32_t tick, int u, bool act,
-                                         long long iu, int ix, int iy, const int (&bsx)[BT], const int (&bsy)[BT], double pg[BT]) {
+                                         long long iu, int ix, int iy, const int (&bsx)[BT], const int (&bsy)[BT],
+                                         const U4 &q0, const U4 &q1, double pg[BT]) {
+    // PRE: q0 / q1 are this walker's calls 0 and 1, already made for the heading of the same tick.
     const int B = uav_count<BT, FAST>(p.B);
 #pragma unroll
     for (int b2 = 0; b2 < BT; b2 += 2) {
@@ -364,12 +379,13 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
                     if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
                 }
             } else {
-                double u0, u1;
-                philox_u2(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING, u0, u1);
+                const U4 q = (PRE && b2 == 0) ? q0 : ((PRE && b2 == 2) ? q1 :
+                             philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING));
+                const double u0 = u53(q.x, q.y);
                 const double t = -2.0 * lm_logc(1.0 - u0, C);      // 1-u0 in [2^-53, 1]: positive, normal
                 const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;   // sqrt(t); t == 0 only when u0 == 0
                 double sa, ca;
-                lm_sincospi(2.0 * u1, C, &sa, &ca);
+                lm_sincospi((double)q.z * (1.0 / 2147483648.0), C, &sa, &ca);   // angle = 2*pi * q.z / 2^32
                 f0 = H.sh_mean + H.sh_sd * (r * ca);
                 f1 = H.sh_mean + H.sh_sd * (r * sa);
             }
@@ -670,6 +686,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
 
     UAV_STAMP(ts3);                                   // UAV move done
     // ---- mobility: n_ticks x next(self.mm); walker and group state stay in registers across ticks ----
+    U4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};   // this walker's Philox calls 0 / 1 of the last tick (heading + fading)
     for (int it = 0; it < n_ticks; ++it) {
         if (has_mobility(MODE)) {
             const bool aggregating = agg != 0;
@@ -693,7 +710,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
                 }
             }
             if (UAV_INJ(p.inj_theta)) hu = hu_inj;                                       // new heading (:508)
-            else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
+            else {
+                const int HB = (B + 1) >> 1;
+                q0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
+                q1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : q0;
+                hu = heading_from(q0, q1, HB);
+            }
             if (gown) group_finish<FAST>(p, C, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);   // :493-521
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }            // :472-473
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }                        // :486-487
@@ -709,7 +731,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     unsigned long long ob = 0ull;
     if (MODE != MODE_WARMUP) {
         double pg[BT];
-        rx_power<BT, PLC, FAST>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, pg);
+        rx_power<BT, PLC, FAST, FAST && has_mobility(MODE)>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, q0, q1, pg);
         const int best = argmax_pg<BT, FAST>(p, pg);
         const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
         if (is_reset(MODE)) {
@@ -870,7 +892,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                     }
                 }
                 if (p.inj_theta) { if (act) hu = p.inj_theta[iu]; }
-                else { double t1; philox_u2(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING, hu, t1); }
+                else {
+                    const int HB = (B + 1) >> 1;
+                    const U4 h0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
+                    const U4 h1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : h0;
+                    hu = heading_from(h0, h1, HB);
+                }
                 ix = (int)x; iy = (int)y;
                 if (act) {
                     st.ue_x[iu] = x; st.ue_y[iu] = y; st.ue_hu[iu] = hu;
@@ -884,7 +911,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
             double pg[BT];
-            rx_power<BT, PLC, FAST>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, pg);
+            { const U4 z = {0u, 0u, 0u, 0u}; rx_power<BT, PLC, FAST, false>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, z, z, pg); }
             const int best = argmax_pg<BT, FAST>(p, pg);
             const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
             if (is_reset(MODE)) {

@@ -59,6 +59,29 @@ static void philox_u2(const UavoState *st, int64_t e, uint32_t tick, uint32_t id
     u[1] = u53(o[2], o[3]);
 }
 
+/* Per-UE draw block of a tick (Philox mode; the product's csrc/uavenv_kernels.h defines the same stream):
+ *   call p of walker u:  q_p = Philox(ctr = (env, tick, u*HB + p, DOM_FADING)),  HB = ceil(B/2)
+ *   q_p.x, q_p.y -> 53-bit uniform of the Box-Muller radius;  q_p.z * 2^-32 -> angle fraction;  q_p.w -> spare
+ *   heading uniform drawn this tick = u53(q_0.w, q_1.w)   (HB >= 2)   or   q_0.w * 2^-32   (HB == 1)
+ * Two Philox calls per UE and tick instead of three (a separate heading call): the 32x32->64 multiplies of Philox
+ * are quarter-rate on CDNA4 and were ~17 % of the step kernel's issue cycles. */
+static void philox_raw(const UavoState *st, int64_t e, uint32_t tick, uint32_t idx, uint32_t dom, uint32_t o[4]) {
+    uint32_t ctr[4] = {st->env_id_base + (uint32_t)e, tick, idx, dom};
+    uint32_t key[2] = {(uint32_t)st->seed, (uint32_t)(st->seed >> 32)};
+    uavo_philox4x32_10(ctr, key, o);
+}
+
+static double heading_uniform(const UavoConfig *cfg, const UavoState *st, int64_t e, uint32_t tick, int u) {
+    const int HB = (cfg->n_bs + 1) / 2;
+    uint32_t o0[4], o1[4];
+    philox_raw(st, e, tick, (uint32_t)(u * HB + 0), DOM_FADING, o0);
+    if (HB >= 2) {
+        philox_raw(st, e, tick, (uint32_t)(u * HB + 1), DOM_FADING, o1);
+        return u53(o0[3], o1[3]);
+    }
+    return (double)o0[3] * (1.0 / 4294967296.0);
+}
+
 /* ---- numpy add.reduce order (np.sum / np.mean at channel.py:216,265): pairwise_sum ---- */
 double uavo_np_pairwise_sum(const double *a, int64_t n) {
     if (n < 8) {
@@ -227,7 +250,7 @@ static void mobility_tick(const UavoConfig *cfg, UavoState *st, int64_t e, const
     }
     for (int u = 0; u < U; ++u) {          /* :508 theta = U(0, 2*pi, NODES) */
         if (inj && inj->theta_u) hu[u] = inj->theta_u[e * U + u];
-        else { double t[2]; philox_u2(st, e, tick, (uint32_t)u, DOM_HEADING, t); hu[u] = t[0]; }
+        else hu[u] = heading_uniform(cfg, st, e, tick, u);
     }
     for (int g = 0; g < Gr; ++g) {         /* :513-521 */
         g_fl[g] = g_fl[g] - g_v[g];
@@ -328,10 +351,10 @@ static void draw_fading(const UavoConfig *cfg, const UavoState *st, int64_t e, u
     /* np.random.normal(mean, sd) (channel.py:240) -> Box-Muller on Philox uniforms, two BSs per call */
     for (int u = 0; u < U; ++u)
         for (int p = 0; p < HB; ++p) {
-            double t[2];
-            philox_u2(st, e, tick, (uint32_t)(u * HB + p), DOM_FADING, t);
-            double r = sqrt(-2.0 * log(1.0 - t[0]));
-            double a = TWO_PI_NP * t[1];
+            uint32_t o[4];
+            philox_raw(st, e, tick, (uint32_t)(u * HB + p), DOM_FADING, o);
+            double r = sqrt(-2.0 * log(1.0 - u53(o[0], o[1])));
+            double a = TWO_PI_NP * ((double)o[2] * (1.0 / 4294967296.0));
             fading[u * B + 2 * p] = cfg->shadow_mean + cfg->shadow_sd * (r * cos(a));
             if (2 * p + 1 < B) fading[u * B + 2 * p + 1] = cfg->shadow_mean + cfg->shadow_sd * (r * sin(a));
         }
