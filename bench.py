@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path with several ranks sharing one GPU)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--n-bs", type=int, default=N_BS, help="secondary measurements only (default = BASELINE workload)")
+    ap.add_argument("--n-ue", type=int, default=N_UE, help="secondary measurements only (default = BASELINE workload)")
     args = ap.parse_args()
 
     import torch
@@ -125,11 +127,14 @@ def main():
 
     E, K, W = args.envs, args.steps, args.warmup
     env_id_base, _ = shard_for_rank(rank, world, E)   # rank r owns global envs [r*E, (r+1)*E): no env-path collective
-    env = BatchedMobiEnv(E, nBS=N_BS, nUE=N_UE, grid_n=GRID, groups=GROUPS, device=dev, seed=SEED,
+    n_bs, n_ue = args.n_bs, args.n_ue
+    baseline_shape = (n_bs, n_ue) == (N_BS, N_UE)
+    groups = GROUPS if baseline_shape else [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
+    env = BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=GRID, groups=groups, device=dev, seed=SEED,
                          env_id_base=env_id_base)
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_act = min(K + W, 512)  # action table resident in HBM, cycled
-    actions = torch.randint(0, env.action_space_dim, (n_act, E), generator=gen, dtype=torch.int64).to(dev)
+    actions = torch.randint(0, min(env.action_space_dim, 2 ** 62), (n_act, E), generator=gen, dtype=torch.int64).to(dev)
     max_step = int(env.cfg.max_step)
 
     def run(n, start):
@@ -156,22 +161,23 @@ def main():
 
     if rank == 0:
         per_launch_s = gpu_ms * 1e-3 / K  # average launch-to-launch time of the step kernel (HIP events)
-        b_step = algorithmic_bytes_per_env_step(N_UE, N_BS, len(GROUPS))
+        b_step = algorithmic_bytes_per_env_step(n_ue, n_bs, len(groups))
         achieved = b_step * E / per_launch_s / 1e9
         line = {
             "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
             "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d batched envs/GPU, 4 UAV x 20 UE (groups 5,5,5,5), G=100, HIP step(), "
-                                   "compact outputs, on-device Philox, one launch per step" % E,
-                       "envs_per_gpu": E, "n_bs": N_BS, "n_ue": N_UE, "grid": GRID, "parallelism": "env-shard x%d" % world},
+            "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=100, HIP step(), "
+                                   "compact outputs, on-device Philox, one launch per step" % (
+                                       E, n_bs, n_ue, ",".join(str(g) for g in groups)),
+                       "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": GRID, "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(E),
-                         "kernel": STEP_KERNEL, "algorithmic_bytes_per_launch": b_step * E,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(E) if baseline_shape else None,
+                         "kernel": STEP_KERNEL if baseline_shape else "env kernel of this shape (secondary measurement)", "algorithmic_bytes_per_launch": b_step * E,
                          "avg_launch_us": per_launch_s * 1e6},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and baseline_shape:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag> [bench args]
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag> [bench args]
 # kernel trace + stats, then two PMC passes (FETCH_SIZE, WRITE_SIZE) -- separate runs, as the guide prescribes.
 set -e
 TAG=$1; shift
@@ -11,5 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/trace
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$TAG/pmc_fetch -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $R/gpurun_out/$TAG/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/pmc_write -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $R/gpurun_out/$TAG/bench_pmc_write.log 2>&1
 cd $R
-python3 tools_prof_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.txt 2>&1 || true
+python3 tools/prof_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.txt 2>&1 || true
 cat gpurun_out/$TAG/summary.txt

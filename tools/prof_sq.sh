@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools_prof_sq.sh <tag> [bench args] -- SQ counter passes for the step kernel
+# usage (GPU box, repo root): bash tools/prof_sq.sh <tag> [bench args] -- SQ counter passes for the step kernel
 set -e
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}

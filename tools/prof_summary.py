@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a tools_prof.sh output directory into a short text summary (kernel stats + HBM traffic)."""
+"""Condenses a tools/prof.sh output directory into a short text summary (kernel stats + HBM traffic)."""
 import csv
 import glob
 import os
