@@ -31,7 +31,7 @@ def algorithmic_bytes_per_env_step(U, B, Gr):
     return 48 * U + 2 * ((U + 7) // 8) + 96 * Gr + 16 * B + 45
 
 
-STEP_KERNEL = "env_kernel_packed<4, 2, true, true>"   # what rocprofv3 names the FAST step kernel of this workload
+STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true>"   # rocprofv3 name (template part) of the step kernel of this workload
 
 
 def measured_traffic(envs):

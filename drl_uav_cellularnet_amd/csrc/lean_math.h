@@ -50,14 +50,19 @@ struct LeanCoef {
     double lg[7], ln2_hi, ln2_lo;   // fdlibm e_log.c
 };
 
+// PIN is a launch-time policy, not a constant of the build: pinning costs ~100 VGPRs (occupancy 2 instead of 4).  It wins
+// when a launch needs at most two wavefronts per SIMD (4096 envs x 20 UEs: 9.35 vs 9.81 us) and loses when more must be
+// resident (65536 envs: 72.1 vs 65.5 us; 4 x 40: 16.0 vs 15.1 us) -- gpurun_out/ab_pin.log, DESIGN.md section 4.
+template <bool PIN>
 UAVENV_HD void lm_pin(double &v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(v));
+    if (PIN) asm volatile("" : "+v"(v));
 #else
     (void)v;
 #endif
 }
 
+template <bool PIN>
 UAVENV_HD LeanCoef lm_make_coef() {
     LeanCoef c = {
         {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c58fp-3, 0x1.c6b08d704a0c0p-5, 0x1.3b2ab6fba4e77p-7, 0x1.5d87fe78a6731p-10,
@@ -70,10 +75,10 @@ UAVENV_HD LeanCoef lm_make_coef() {
         {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01,
          1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01},
         6.93147180369123816490e-01, 1.90821492927058770002e-10};
-    for (int k = 0; k < 13; ++k) lm_pin(c.e2[k]);
-    for (int k = 0; k < 8; ++k) { lm_pin(c.sp[k]); lm_pin(c.cp[k]); }
-    for (int k = 0; k < 7; ++k) lm_pin(c.lg[k]);
-    lm_pin(c.ln2_hi); lm_pin(c.ln2_lo);
+    for (int k = 0; k < 13; ++k) lm_pin<PIN>(c.e2[k]);
+    for (int k = 0; k < 8; ++k) { lm_pin<PIN>(c.sp[k]); lm_pin<PIN>(c.cp[k]); }
+    for (int k = 0; k < 7; ++k) lm_pin<PIN>(c.lg[k]);
+    lm_pin<PIN>(c.ln2_hi); lm_pin<PIN>(c.ln2_lo);
     return c;
 }
 

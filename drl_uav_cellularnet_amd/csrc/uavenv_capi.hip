@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,6 +25,7 @@ struct uavenv {
     int bt;  // template bound on B
     bool plc;  // pl_b == 30: cube path-loss kernel variant
     bool packed;  // U <= 64 and U >= max(B, Gr): env_kernel_packed with kp.epw envs per wavefront
+    long long n_simd;  // 4 x compute units of the device: wavefront demand per SIMD decides the PIN variant
     char *blob;
     int32_t *bs_init_dev;
     long long *act_pow_dev;
@@ -135,6 +137,11 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     uavenv *h = new (std::nothrow) uavenv();
     if (!h) return fail(UAVENV_E_NOMEM, "create: host allocation failed");
     h->cfg = *cfg; h->N = n_envs; h->device = device; h->seed = seed; h->env_id_base = env_id_base;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+        h->n_simd = 4ll * cus;
+    }
     const size_t U = (size_t)cfg->n_ue, B = (size_t)cfg->n_bs;
     const size_t W64 = (U + 63) / 64;
     h->bt = B <= 4 ? 4 : B <= 8 ? 8 : B <= 16 ? 16 : 32;
@@ -289,8 +296,8 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
         const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4
         if (h->packed) {
-            if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, PK_ARGS);
-            else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, PK_ARGS);
+            if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true, false>), dim3(grid), blk, 0, s, PK_ARGS);
+            else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false, false>), dim3(grid), blk, 0, s, PK_ARGS);
         } else {
             hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true>), dim3(grid), blk, 0, s, p);
         }
@@ -299,10 +306,14 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     }
     constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
     const bool fast = call_is_fast(p) && (p.B == h->bt);   // FAST kernels are compiled for B == BT exactly
+    // PIN variant (constants pinned in VGPRs, occupancy 2) only when the launch needs <= 2 wavefronts per SIMD
+    bool pin = fast && (waves <= 2 * h->n_simd);
+    if (const char *f = std::getenv("UAVENV_FORCE_PIN")) pin = fast && (f[0] == '1');   // experiments only
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
-        if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true>), dim3(grid), blk, 0, s, PK_ARGS);          \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false>), dim3(grid), blk, 0, s, PK_ARGS);              \
+        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true>), dim3(grid), blk, 0, s, PK_ARGS);     \
+        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false>), dim3(grid), blk, 0, s, PK_ARGS); \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false>), dim3(grid), blk, 0, s, PK_ARGS);       \
     } while (0)
 #define UAVENV_LAUNCH(BT_)                                                                                       \
     do {                                                                                                         \

@@ -179,12 +179,13 @@ __device__ __forceinline__ void kernarg_warm() {
 struct HotConst {
     double vel, aggr, maxc, sh_mean, sh_sd, c_exp, k_pl, k_0, pl_dis2, pl_exp_ln, noise, db_per_ln, ho_thr, out_thr, gw;
 };
+template <bool PIN>
 __device__ __forceinline__ HotConst make_hot(const KParams &p) {
     HotConst h = {p.ue_velocity, p.aggregation, (double)p.G, p.shadow_mean, p.shadow_sd, p.c_exp, p.k_pl, p.k_0,
                   p.pl_dis2, p.pl_exp_ln, p.noise_watt, p.db_per_ln, p.ho_thresh_db, p.out_thresh, p.grid_width};
-    lm_pin(h.vel); lm_pin(h.aggr); lm_pin(h.maxc); lm_pin(h.sh_mean); lm_pin(h.sh_sd); lm_pin(h.c_exp); lm_pin(h.k_pl);
-    lm_pin(h.k_0); lm_pin(h.pl_dis2); lm_pin(h.pl_exp_ln); lm_pin(h.noise); lm_pin(h.db_per_ln); lm_pin(h.ho_thr);
-    lm_pin(h.out_thr); lm_pin(h.gw);
+    lm_pin<PIN>(h.vel); lm_pin<PIN>(h.aggr); lm_pin<PIN>(h.maxc); lm_pin<PIN>(h.sh_mean); lm_pin<PIN>(h.sh_sd); lm_pin<PIN>(h.c_exp); lm_pin<PIN>(h.k_pl);
+    lm_pin<PIN>(h.k_0); lm_pin<PIN>(h.pl_dis2); lm_pin<PIN>(h.pl_exp_ln); lm_pin<PIN>(h.noise); lm_pin<PIN>(h.db_per_ln); lm_pin<PIN>(h.ho_thr);
+    lm_pin<PIN>(h.out_thr); lm_pin<PIN>(h.gw);
     return h;
 }
 
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // Host guarantees U >= max(B, Gr) (owner lanes live inside the slot) and EPW*U <= 64.
 // BT: compile-time bound on B.  PLC: pl_b == 30 (channel.py:47) => d^-3 by sqrt.
 // ================================================================================================
-template <int BT, int MODE, bool PLC, bool FAST>
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
                                                                               int Gr, int B_rt, const KParams p) {
@@ -640,8 +641,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     // Only now touch the parameter struct: its (cold) kernarg fetch overlaps the global loads issued above.
     __builtin_amdgcn_sched_barrier(0);
     kernarg_warm<(int)sizeof(KParams)>();
-    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
-    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
+    const LeanCoef C = lm_make_coef<PIN>();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
+    const HotConst H = make_hot<PIN>(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
     const double MAXC = H.maxc;
     UAV_DRAIN_VM();
     UAV_STAMP(ts2);                                   // every load of the load phase has returned
@@ -804,8 +805,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
     if (e >= p.N) return;
     if (is_reset(MODE)) { if (p.mask != nullptr && p.mask[e] == 0) return; }
-    const LeanCoef C = lm_make_coef();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
-    const HotConst H = make_hot(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
+    const LeanCoef C = lm_make_coef<false>();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
+    const HotConst H = make_hot<false>(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
 
     const int U = p.U, B = p.B, Gr = p.Gr;
     const double MAXC = H.maxc;
@@ -1002,8 +1003,8 @@ __global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const d
     const long long e = t / cells;
     const long long c = t - e * cells;
     const int x = 1 + (int)(c / W), y = 1 + (int)(c % W);            // :416-417 range(xMin, xMax) x range(yMin, yMax)
-    const LeanCoef C = lm_make_coef();
-    const HotConst H = make_hot(p);
+    const LeanCoef C = lm_make_coef<false>();
+    const HotConst H = make_hot<false>(p);
     int d2i[BT];
     int near = 0;                                                   // :418-422 np.argmin(dist): first minimum
 #pragma unroll

@@ -42,7 +42,7 @@ int main() {
     // near 1 (SINR near 0 dB: the region the 1e-5 relative bound of the float32 output is sensitive to)
     run("log_near_one", [](double x) { return uavk::lm_log(x); }, [](long double x) { return std::log(x); },
         [&](std::mt19937_64 &g) { return 1.0 + (u01(g) - 0.5) * 1e-3; }, n);
-    const uavk::LeanCoef C = uavk::lm_make_coef();
+    const uavk::LeanCoef C = uavk::lm_make_coef<false>();
     run("logc_sinr_ratio", [&](double x) { return uavk::lm_logc(x, C); }, [](long double x) { return std::log(x); },
         [&](std::mt19937_64 &g) { return std::pow(10.0, -20.0 + 33.0 * u01(g)); }, n);
     // 10^(-f/10) = 2^(c*f), f ~ N(0,2) -> |x| < ~4; generic path-loss exponent adds down to ~ -40
