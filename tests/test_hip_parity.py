@@ -129,6 +129,11 @@ PHILOX_SHAPES = [
     (7, 33, 64, 8, 24, {}),                    # packed, 1 env per wavefront, BT = 8 with B = 7, ragged groups
     (16, 200, 100, 8, 24, {}),                 # multi-pass (4 passes), BT = 16, 64-bit action digits
     (16, 12, 64, 8, 24, {}),                   # multi-pass because U < B (owner lanes would not fit a slot)
+    (4, 64, 100, 5, 24, {}),                   # packed, U = 64 exactly: full-wavefront slot mask
+    (4, 65, 100, 5, 24, {}),                   # multi-pass with ONE walker in the second pass
+    (4, 20, 100, 1, 24, {}),                   # a single env (one live slot of three)
+    (1, 8, 32, 9, 24, {}),                     # one UAV: HB = 1 (32-bit heading word), no interference terms
+    (3, 20, 64, 12, 24, {}),                   # B = 3 < BT = 4: checked variant (FAST needs B == BT)
     (4, 20, 100, 32, 40, {"pl_b": 37.6, "pl_a": 15.3}),  # generic path-loss exponent (PLC = false), packed
     (16, 200, 100, 4, 12, {"pl_b": 37.6}),     # generic path-loss exponent, multi-pass
 ]
@@ -146,7 +151,7 @@ def test_hip_matches_oracle_on_philox_streams(shape):
         groups = [U // 4] * 3 + [U - 3 * (U // 4)]
     bs_init = None
     if B != 4:
-        side = int(np.ceil(np.sqrt(B)))
+        side = max(1, int(np.ceil(np.sqrt(B))))
         bs_init = [(G // (2 * side) + (b // side) * (G // side), G // (2 * side) + (b % side) * (G // side))
                    for b in range(B)]
     seed, base = 0xC0FFEE1234, 1000
