@@ -230,6 +230,15 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_obs_dense(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def dense_obs_update(self, buf):
+        """Bring ``buf`` (the tensor the previous dense_obs / dense_obs_update call of this env wrote) up to date IN PLACE:
+        only the <= nUE + nBS cells per env that changed are touched, instead of rewriting N*(nBS+1)*G*G floats."""
+        N, B, G = self.n_envs, self.nBS, self.grid_n
+        if buf.dtype != torch.float32 or buf.numel() != N * (B + 1) * G * G or not buf.is_contiguous():
+            raise ValueError("buf must be the contiguous float32 [N, nBS+1, G, G] tensor dense_obs returned")
+        _capi.check(self._lib.uavenv_obs_dense_update(self._h, buf.data_ptr(), self._stream()))
+        return buf
+
     def sinr_area(self, fading=None, dtype=torch.float32):
         """LTEChannel.GetSinrInArea (channel.py:411-433) for every env: [N, G, G] dB, nearest-UAV SINR per cell with
         fresh shadowing (row / column 0 are 0, as in the reference).  ``fading``: injected draws [N, (G-1)^2, B]."""

@@ -30,6 +30,7 @@ struct uavenv {
     int32_t *bs_init_dev;
     long long *act_pow_dev;
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
+    int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
 };
@@ -245,6 +246,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->bs_init_dev);
     (void)hipFree(h->act_pow_dev);
     (void)hipFree(h->gid_dev);
+    if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
     delete h;
 }
 
@@ -403,15 +405,35 @@ extern "C" int uavenv_reset_trace(uavenv_t *h, const uint8_t *mask_dev, const in
     return launch_env<MODE_RESET_TRACE>(h, p, (hipStream_t)stream);
 }
 
+static int ensure_obs_prev(uavenv_t *h) {
+    if (h->obs_prev_dev) return UAVENV_OK;
+    const size_t bytes = (size_t)h->kp.N * (h->kp.U + h->kp.B) * sizeof(int32_t);
+    if (hipMalloc((void **)&h->obs_prev_dev, bytes) != hipSuccess) return fail(UAVENV_E_NOMEM, "obs_dense: hipMalloc cell list");
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense: null handle or buffer");
     DeviceGuard guard(h->device);
+    if (int rc = ensure_obs_prev(h)) return rc;   // (first call only; not inside a captured region)
     const KParams &k = h->kp;
     const size_t bytes = (size_t)k.N * (k.B + 1) * k.G * k.G * sizeof(float);
     HIP_TRY(hipMemsetAsync(obs_dev, 0, bytes, (hipStream_t)stream));
     const long long total = k.N * (k.U + k.B);
-    hipLaunchKernelGGL(obs_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k.N,
-                       k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, obs_dev);
+    hipLaunchKernelGGL((obs_cells_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, h->obs_prev_dev, obs_dev);
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream) {
+    if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense_update: null handle or buffer");
+    if (!h->obs_prev_dev) return fail(UAVENV_E_INVALID, "obs_dense_update: call uavenv_obs_dense on this buffer first");
+    DeviceGuard guard(h->device);
+    const KParams &k = h->kp;
+    const long long total = k.N * (k.U + k.B);
+    hipLaunchKernelGGL((obs_cells_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, h->obs_prev_dev, obs_dev);
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

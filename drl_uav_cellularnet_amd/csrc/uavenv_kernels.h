@@ -967,24 +967,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
 // ================================================================================================
 // env.state planes: GetGridMap (ue_mobility.py:173-188) + GetCurrentAssociationMap (channel.py:387-409).
-// obs is zero-filled by the caller (hipMemsetAsync); one thread per (env, node); counts add.
 // ================================================================================================
-__global__ __launch_bounds__(256) void obs_scatter_kernel(long long N, int U, int B, int G, const int32_t *bs_xy,
-                                                          const int16_t *ue_xy, const int8_t *serving, float *obs) {
+// Flat index (inside one env's (B+1, G, G) block) of node k: k < B the UAV cells of plane 0, else UE k-B in the plane
+// of its serving UAV; -1 when the cell is outside the grid (the reference would raise IndexError).
+__device__ __forceinline__ int obs_cell(long long e, int k, int U, int B, int G, const int32_t *bs_xy, const int16_t *ue_xy,
+                                        const int8_t *serving) {
+    int x, y, pl;
+    if (k < B) { x = bs_xy[(e * B + k) * 2]; y = bs_xy[(e * B + k) * 2 + 1]; pl = 0; }
+    else { const int u = k - B; x = ue_xy[(e * U + u) * 2]; y = ue_xy[(e * U + u) * 2 + 1]; pl = 1 + serving[e * U + u]; }
+    if (x < 0 || x >= G || y < 0 || y >= G) return -1;
+    return (pl * G + x) * G + y;
+}
+
+// Full write (after the caller's memset) that also records the written cells, and the in-place update that moves only
+// the cells that changed.  Counts are small integers in float32, so +-1.0f is exact and the order of atomics is irrelevant.
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void obs_cells_kernel(long long N, int U, int B, int G, const int32_t *bs_xy,
+                                                        const int16_t *ue_xy, const int8_t *serving, int32_t *prev, float *obs) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = U + B;
     if (t >= N * per) return;
     const long long e = t / per;
     const int k = (int)(t - e * per);
-    const long long plane = (long long)G * G;
-    int x, y, pl;
-    if (k < B) { x = bs_xy[(e * B + k) * 2]; y = bs_xy[(e * B + k) * 2 + 1]; pl = 0; }
-    else {
-        const int u = k - B;
-        x = ue_xy[(e * U + u) * 2]; y = ue_xy[(e * U + u) * 2 + 1]; pl = 1 + serving[e * U + u];
+    const long long base = e * (long long)(B + 1) * G * G;
+    const int now = obs_cell(e, k, U, B, G, bs_xy, ue_xy, serving);
+    if (UPDATE) {
+        const int old = prev[t];
+        if (old == now) return;
+        if (old >= 0) atomicAdd(&obs[base + old], -1.0f);
     }
-    if (x < 0 || x >= G || y < 0 || y >= G) return;  // the reference would raise IndexError
-    atomicAdd(&obs[(e * (B + 1) + pl) * plane + (long long)x * G + y], 1.0f);
+    if (now >= 0) atomicAdd(&obs[base + now], 1.0f);
+    prev[t] = now;
 }
 
 // ================================================================================================

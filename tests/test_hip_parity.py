@@ -336,3 +336,28 @@ def test_hip_sinr_area_matches_oracle_on_philox_streams():
     want = orc.sinr_area()
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
     assert float(np.abs(want).max()) > 10.0
+
+
+def test_dense_obs_incremental_update_equals_full_rewrite():
+    """uavenv_obs_dense_update moves only the changed cells; after any number of steps / masked resets the buffer must
+    equal a full rewrite (and therefore the reference's state tensor, which the full rewrite is pinned to)."""
+    torch = _torch()
+    N = 300
+    env = _make(N, nBS=4, nUE=20, grid_n=100, max_step=7)
+    buf = env.dense_obs()                                   # first use: full write, records the cells
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(20):
+        a = torch.randint(0, 625, (N,), generator=gen).to(env.device)
+        _, _, done, _ = env.step(a)
+        if t % 6 == 5:
+            env.reset(mask=(torch.arange(N, device=env.device) % 3 == 0))
+        env.dense_obs_update(buf)
+        assert torch.equal(buf, _full(env)), "step %d" % t
+    assert float(buf.min()) >= 0.0 and float(buf[:, 0].sum()) == 4.0 * N and float(buf[:, 1:].sum()) == 20.0 * N
+
+
+def _full(env):
+    # A full rewrite for comparison must not go through `env` itself: the handle remembers the cells of its LAST obs call,
+    # so writing another buffer would break the lineage of `buf` (documented in include/uavenv.h).  A clone has its own handle.
+    twin = env.clone()
+    return twin.dense_obs()
