@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path with several ranks sharing one GPU)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even at "
+                    "world size 1 (exercises the RCCL init / barrier / max-reduce path on a one-GPU box)")
     ap.add_argument("--n-bs", type=int, default=N_BS, help="secondary measurements only (default = BASELINE workload)")
     ap.add_argument("--n-ue", type=int, default=N_UE, help="secondary measurements only (default = BASELINE workload)")
     args = ap.parse_args()
@@ -106,10 +108,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.force_device is not None:
             local_rank = args.force_device
         torch.cuda.set_device(local_rank)
