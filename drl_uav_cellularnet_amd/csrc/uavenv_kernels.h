@@ -199,7 +199,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ double slot_sum(double v, int ul, int U) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        if (off >= U) break;                       // wave-uniform: an offset >= U can never stay inside the slot
         const double t = __shfl_down(v, off, 64);
         if (ul + off < U) v += t;
     }
