@@ -7,12 +7,21 @@
 //                      ("slots": lanes [s*U, (s+1)*U)), e.g. 3 envs at 20 UEs, 1 env at 40 UEs.  Ballots are
 //                      masked with the slot's lane mask, sums are segmented shuffle reductions.
 //   env_kernel_multipass (U > 64): one env per wavefront, walkers in passes of 64 (200 UEs: 4 passes).
-//   In a slot, lanes 0..Gr-1 also own one RPGM group each and lanes 0..B-1 one UAV each.
-//   UAV cells are staged in LDS (one row per slot) and read back in the per-UE path-loss loop; received
-//   powers of the BT UAVs live in registers (BT = template bound on B, so every index is static).
+//   In a slot, lanes 0..Gr-1 also own one RPGM group each and lanes 0..B-1 one UAV each (they load / store it).
+//   UAV cells and the received powers of the BT UAVs live in registers (BT = template bound on B, every index
+//   static).  For B <= 8 every lane replays BS_move for its own env serially (no cross-lane traffic, no LDS); for
+//   B > 8 the cooperative one-UAV-per-lane form stages the cells in LDS and copies the row into registers.
 //   No MFMA: there is no dense contraction on this path.  Arithmetic is float64 throughout (SURVEY.md H2:
 //   float32 breaks the 1e-5 relative bound near 0 dB and flips handover/outage decisions); outputs are
-//   rounded to float32 once.
+//   rounded to float32 once.  Transcendentals: csrc/lean_math.h (accuracy measured in tests/test_lean_math.py).
+//
+// Kernel variants (template parameters, chosen per launch in uavenv_capi.hip):
+//   BT    bound on B (4/8/16/32)         PLC   path-loss exponent 30 => d^-3 by rsqrt, no log
+//   FAST  no injected draws, all nine standard outputs, B == BT: no run-time pointer tests, no `b < B` guards
+//   PIN   polynomial coefficients + hot constants pinned in VGPRs (wins iff <= 2 wavefronts per SIMD)
+// Structure of the packed kernel (why: DESIGN.md section 4, profiles/r01_v*_phase_stamps.txt): leading scalar
+// arguments are kernarg-PRELOADED; every global load is issued from them first (state addresses = slab base +
+// csrc/state_layout.h), the parameter struct is fetched while those loads are in flight, all stores form one phase.
 //
 // What the code follows in the reference (/root/reference):
 //   mobility tick      ue_mobility.py:453-523     UAV move   ue_mobility.py:191-271,310-336
