@@ -361,3 +361,48 @@ def _full(env):
     # so writing another buffer would break the lineage of `buf` (documented in include/uavenv.h).  A clone has its own handle.
     twin = env.clone()
     return twin.dense_obs()
+
+
+@pytest.mark.parametrize("shape", [(4, 20, 100, 200), (4, 40, 100, 64), (8, 24, 64, 48), (16, 32, 100, 24)],
+                         ids=lambda s: "B%dU%dN%d" % (s[0], s[1], s[3]))
+@pytest.mark.parametrize("pin", ["1", "0"], ids=["pinned", "unpinned"])
+def test_production_fast_variant_matches_oracle(shape, pin, monkeypatch):
+    """The kernels a user actually runs (FAST: no injection, the nine standard float32/int outputs, B == BT), in both
+    their pinned and unpinned builds, against the oracle on identical Philox streams.  (The other oracle comparisons ask
+    for float64 copies and therefore go through the checked variant.)"""
+    torch = _torch()
+    from oracle import oracle as O
+
+    monkeypatch.setenv("UAVENV_FORCE_PIN", pin)          # read by the launcher at every launch
+    B, U, G, N = shape
+    side = int(np.ceil(np.sqrt(B)))
+    bs_init = None if B == 4 else [(G // (2 * side) + (b // side) * (G // side), G // (2 * side) + (b % side) * (G // side))
+                                   for b in range(B)]
+    env = _make(N, nBS=B, nUE=U, grid_n=G, bs_init=bs_init, seed=2024, env_id_base=5)   # f64_outputs=False -> FAST
+    assert "cur_sinr_f64" not in env.out
+    orc = O.OracleEnv(O.make_config(B, U, G, groups=[U // 4] * 4, bs_init=bs_init), N, seed=2024, env_id_base=5)
+    oo = orc.construct()
+    rs = np.random.RandomState(11)
+    T = 48
+    for t in range(T):
+        digits = rs.randint(0, 5, size=(N, B)).astype(np.int64)
+        act = np.zeros(N, np.int64)
+        for b in range(B):
+            act = act * 5 + digits[:, b]
+        if t == T // 2:
+            mask = (np.arange(N) % 3 == 1).astype(np.uint8)
+            env.reset(mask=mask)
+            orc.reset(mask=mask)
+        env.step(torch.as_tensor(act, device=env.device))
+        oo = orc.step(act)
+        torch.cuda.synchronize()
+        g = {k: v.cpu().numpy() for k, v in env.out.items()}
+        for k in ("ue_xy", "bs_xy", "serving", "step_n", "n_out", "done"):
+            np.testing.assert_array_equal(g[k], oo[k], err_msg="step %d %s" % (t, k))
+        for k in ("cur_sinr", "mean_sinr", "reward"):
+            np.testing.assert_allclose(g[k], oo[k], rtol=F32_RTOL, atol=0, err_msg="step %d %s" % (t, k))
+    s = env.state_fields()
+    for k in ("ue_x", "ue_y", "g_x", "g_y", "g_fl", "g_v", "g_cos", "g_sin"):
+        np.testing.assert_allclose(s[k], orc.s[k], rtol=0, atol=1e-9, err_msg=k)
+    for k in ("agg", "deagg", "tick", "bs_xy", "serving", "fifo_depth", "out_bits", "step_n", "ue_xy"):
+        np.testing.assert_array_equal(s[k], orc.s[k], err_msg=k)
