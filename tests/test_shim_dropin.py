@@ -202,3 +202,30 @@ def test_shim_get_sinr_in_area_shape_and_determinism():
     assert m[bx, by] > 60.0                                           # a cell under a UAV: d = 0 -> loss 0
     with pytest.raises(NotImplementedError):
         env.channel.GetSinrInArea(info.bs_loc + 1)
+
+
+def test_eval_harness_like_main_test_py(tmp_path):
+    """BASELINE config 1 plumbing: synthesise a trace, replay it with step_test under a greedy actor, save what
+    main_test.py saves (:46-113)."""
+    _need_gpu()
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_eval", os.path.join(root, "tools", "run_eval.py"))
+    run_eval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run_eval)
+    trace = run_eval.make_trace(n_rows=64)
+    assert trace.shape == (64, 40, 2) and trace.dtype == np.int16 and trace.min() >= 0 and trace.max() <= 99
+    assert (np.abs(np.diff(trace.astype(int), axis=0)) <= 3).all()          # <= 2.8 cells per tick (1 + 1 + 0.8)
+    out = os.path.join(tmp_path, "eval")
+    res = run_eval.run_test(trace, out, max_step=50, area_every=25)
+    assert len(res["reward"]) == 51                                         # `while step <= MAX_STEP` (:69)
+    assert res["sinr"].shape == (51, 40) and res["ue_location"].shape == (51, 40, 2) and res["bs_location"].shape == (51, 4, 3)
+    assert res["sinr_area"].shape == (3, 100, 100)                           # steps 0, 25, 50
+    np.testing.assert_array_equal(res["ue_location"], trace[:51])            # step_test replays trace[step_n] (:202-203)
+    for name in ("reward", "decomposed_reward", "sinr", "time", "outage_fraction", "ue_location", "bs_location",
+                 "action", "sinr_area"):
+        assert os.path.isfile(os.path.join(out, name + ".npy"))
+    res2 = run_eval.run_test(trace, os.path.join(tmp_path, "eval2"), max_step=50, area_every=25)
+    np.testing.assert_array_equal(res["reward"], res2["reward"])             # greedy + seeded env: reproducible
