@@ -73,10 +73,10 @@ class MobiEnvironment:
         from .batched_env import BatchedMobiEnv
 
         if mobility_model == "read_trace":
-            assert test_mobi_file_name                                  # mobile_env.py:84
-            if isinstance(test_mobi_file_name, np.ndarray):
+            if isinstance(test_mobi_file_name, np.ndarray):             # extension: an in-memory trace (also used by deepcopy)
                 self.ueLoc_trace = np.asarray(test_mobi_file_name)
             else:
+                assert test_mobi_file_name                              # mobile_env.py:84
                 self.ueLoc_trace = np.load(test_mobi_file_name, allow_pickle=False)
             if self.ueLoc_trace.ndim != 3 or self.ueLoc_trace.shape[1] < self.nUE or self.ueLoc_trace.shape[2] < 2:
                 raise ValueError("trace must be (T, >=nUE, 2|3) integer cells (mobile_env.py:85-88)")

@@ -229,3 +229,23 @@ def test_eval_harness_like_main_test_py(tmp_path):
         assert os.path.isfile(os.path.join(out, name + ".npy"))
     res2 = run_eval.run_test(trace, os.path.join(tmp_path, "eval2"), max_step=50, area_every=25)
     np.testing.assert_array_equal(res["reward"], res2["reward"])             # greedy + seeded env: reproducible
+
+
+def test_deepcopy_of_a_read_trace_env_like_gradient_py():
+    """gradient.py:42,61 builds a read_trace env and Choose_Act_Gradient deep-copies it every step (:15)."""
+    _need_gpu()
+    from drl_uav_cellularnet_amd import MobiEnvironment
+    from drl_uav_cellularnet_amd.heuristics import choose_act_gradient
+
+    fx, _ = _load("ref_trace_4x40_g100_seed6")
+    env = MobiEnvironment(4, 40, 100, "read_trace", fx["trace"], seed=9)     # in-memory trace
+    env.reset()
+    for _ in range(3):
+        env.step_test(choose_act_gradient(env), False)                        # deep-copies the env inside
+    twin = copy.deepcopy(env)
+    assert twin.mobility_model == "read_trace" and twin.step_n == env.step_n == 3
+    s1, r1, _, i1 = env.step_test(100, False)
+    s2, r2, _, i2 = twin.step_test(100, False)
+    np.testing.assert_array_equal(s1, s2)
+    assert r1 == r2
+    np.testing.assert_array_equal(i1.ue_loc, fx["trace"][3])
