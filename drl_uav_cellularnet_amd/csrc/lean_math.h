@@ -82,6 +82,21 @@ UAVENV_HD LeanCoef lm_make_coef() {
     return c;
 }
 
+// a / b for finite a (either sign, or 0) and positive NORMAL b, quotient normal or 0 (no scaling, no fix-up: the IEEE sequence
+// hipcc emits for `/` spends 11 VALU instructions on ranges the env never produces).  r = rcp(b) refined by one Newton
+// step, q = a*r corrected by one residual step: 6 instructions, <= 1 ulp (measured in tests/test_lean_math.py).
+UAVENV_HD double lm_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+#else
+    double r = (double)(float)(1.0 / b);          // host stand-in with a deliberately poor (24-bit) seed
+#endif
+    r = fma(fma(-b, r, 1.0), r, r);               // Newton: error squared
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);              // residual correction
+}
+
 UAVENV_HD double lm_xor_sign(double v, unsigned long long sign_bit) {
     unsigned long long b;
     __builtin_memcpy(&b, &v, 8);
@@ -130,7 +145,7 @@ UAVENV_HD double lm_logc(double x, const LeanCoef &c) {
     m = low ? m + m : m;
     k = low ? k - 1 : k;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = lm_div(f, 2.0 + f);        // 2+f in [1.70, 2.42)
     const double z = s * s, w = z * z;
     const double t1 = w * (c.lg[1] + w * (c.lg[3] + w * c.lg[5]));
     const double t2 = z * (c.lg[0] + w * (c.lg[2] + w * (c.lg[4] + w * c.lg[6])));

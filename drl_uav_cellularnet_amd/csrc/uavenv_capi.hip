@@ -209,6 +209,8 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.pl_exp_ln = (cfg->pl_b / 10.0) * 0.5 / std::log(2.0);  // d^(-pl_b/10) = 2^(-pl_exp_ln * ln(d^2))
     k.pl_dis2 = cfg->pl_dis < 0.0 ? -1.0 : cfg->pl_dis * cfg->pl_dis;  // d > pl_dis  <=>  d^2 > pl_dis2 (d >= 0)
     k.db_per_ln = 10.0 / std::log(10.0);     // 10*log10(x) = db_per_ln * ln(x)
+    k.inv_U = 1.0 / (double)cfg->n_ue;
+    k.inv_U20 = 1.0 / (20.0 * (double)cfg->n_ue);
     h->plc = (cfg->pl_b == 30.0);
     k.pl_a = cfg->pl_a; k.pl_b = cfg->pl_b; k.pl_dis = cfg->pl_dis; k.antenna_gain = cfg->antenna_gain;
     k.eq_loss = cfg->eq_loss; k.shadow_mean = cfg->shadow_mean; k.shadow_sd = cfg->shadow_sd;

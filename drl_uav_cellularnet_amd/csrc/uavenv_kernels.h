@@ -84,6 +84,7 @@ struct KParams {
     int max_step, bs_step, min_bs_dist2, n_act, agg_init, deagg_len, agg_len;
     double grid_width, p_bs_watt, noise_watt, pl_a, pl_b, pl_dis, antenna_gain, eq_loss;
     double k_pl, k_0, c_exp, pl_exp_ln, pl_dis2, db_per_ln;  // folded constants, see rx_power() / sinr_db()
+    double inv_U, inv_U20;           // 1/U and 1/(20 U): mean and reward terms by one multiply each (env_finish)
     double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
     long long N;
     uint32_t key0, key1, env_id_base;
@@ -448,7 +449,7 @@ __device__ __forceinline__ double sinr_db(const KParams &p, const HotConst &H, c
         interf += (j != x && j < B) ? pg[j] : 0.0;
         px = (j == x) ? pg[j] : px;
     }
-    return H.db_per_ln * lm_logc(px / (H.noise + interf), C);   // 10*log10(x) = (10/ln 10) * ln x
+    return H.db_per_ln * lm_logc(lm_div(px, H.noise + interf), C);   // 10*log10(x) = (10/ln 10) * ln x; both operands normal
 }
 
 // bestBS_buf push + handover decision for one UE (channel.py:148-167).  r0..r2 = FIFO rows, oldest first.
@@ -471,7 +472,7 @@ __device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st
     if (is_reset(MODE)) {
         st.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
         st.step_n[e] = 0;                                      // mobile_env.py:146
-        const double mean = sum_cur / (double)p.U;
+        const double mean = sum_cur * p.inv_U;
         if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = 0;
         if (UAV_OUT(p.out.reward)) p.out.reward[e] = 0.f;
         if (UAV_OUT64(p.out.reward_f64)) p.out.reward_f64[e] = 0.0;
@@ -482,9 +483,9 @@ __device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st
     }
     if (is_step(MODE)) {
         if (depth < 3) st.fifo_depth[e] = depth + 1;
-        const double mean = sum_cur / (double)p.U;            // channel.py:216
-        const double r0 = mean / 20.0;                        // mobile_env.py:165
-        const double r1 = -1.0 * (double)n_outage / (double)p.U;  // mobile_env.py:167
+        const double mean = sum_cur * p.inv_U;                // channel.py:216 (np.mean; <= 1 ulp from sum/U)
+        const double r0 = sum_cur * p.inv_U20;                // mobile_env.py:165  mean / 20
+        const double r1 = -((double)n_outage * p.inv_U);      // mobile_env.py:167  -1.0 * nOut / nUE
         double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181

@@ -62,6 +62,23 @@ int main() {
                              cr = std::cos(3.14159265358979323846264338327950288L * r);
                              switch (iq & 3) { case 0: return cr; case 1: return -sr; case 2: return -cr; default: return sr; } },
         [&](std::mt19937_64 &g) { return 2.0 * u01(g); }, n);
+    // lm_div on the operand ranges the kernels feed it: f/(2+f) inside the log, S/(N+I) for the SINR
+    {
+        std::mt19937_64 rng(99);
+        double worst = 0, sum = 0;
+        const int m = 2000000;
+        for (int i = 0; i < m; ++i) {
+            const bool logcase = (i & 1) != 0;
+            const double f = logcase ? (-0.2928932188134524 + 0.7071067811865476 * u01(rng)) : 0.0;   // m-1, m in [sqrt(1/2), sqrt 2)
+            const double a = logcase ? std::fabs(f) + 1e-300 : std::pow(10.0, -18.0 + 18.0 * u01(rng));
+            const double b = logcase ? 2.0 + f : std::pow(10.0, -16.0 + 14.0 * u01(rng));
+            const long double ref = (long double)a / (long double)b;
+            const double err = std::fabs((double)((long double)uavk::lm_div(a, b) - ref)) / ulp_of((double)ref);
+            if (err > worst) worst = err;
+            sum += err;
+        }
+        std::printf("lm_div %d %.4f %.4f\n", m, worst, sum / m);
+    }
     run("rsqrt_dist2", [](double x) { return uavk::lm_rsqrt(x); }, [](long double x) { return 1.0L / std::sqrt(x); },
         [&](std::mt19937_64 &g) { return 25.0 * (double)(1 + g() % 2000000); }, n);
     // exact multiply-shift division used for the action digits: every divisor 2..9, dense + random + edge dividends
