@@ -136,16 +136,25 @@ PHILOX_SHAPES = [
     (3, 20, 64, 12, 24, {}),                   # B = 3 < BT = 4: checked variant (FAST needs B == BT)
     (4, 20, 100, 32, 40, {"pl_b": 37.6, "pl_a": 15.3}),  # generic path-loss exponent (PLC = false), packed
     (16, 200, 100, 4, 12, {"pl_b": 37.6}),     # generic path-loss exponent, multi-pass
+    # n_act = 9: digits 5..8 are the double steps of BS_move (ue_mobility.py:238-253); mobile_env.py only ever uses N_ACT = 5
+    (4, 20, 100, 33, 40, {"n_act": 9}),        # packed FAST kernel, all nine digits
+    (4, 20, 16, 33, 80, {"n_act": 9}),         # 16 x 16 grid: walls and the min-distance rule fire on most steps
+    (4, 20, 16, 33, 80, {"n_act": 9, "bs_init": [(1, 1), (1, 15), (15, 1), (8, 8)]}),  # UAVs start ON the boundary: only the
+                                               # MOVED coordinate is range-checked (:221-253), so they may slide along a wall
+    (7, 33, 64, 8, 40, {"n_act": 9}),          # checked variant (B = 7 < BT = 8)
+    (16, 200, 100, 4, 12, {"n_act": 9}),       # multi-pass, 9^16 needs the 64-bit digit path
 ]
 
 
-@pytest.mark.parametrize("shape", PHILOX_SHAPES, ids=lambda s: "B%dU%dG%dN%d%s" % (s[0], s[1], s[2], s[3], "gen" if s[5] else ""))
+@pytest.mark.parametrize("shape", PHILOX_SHAPES, ids=lambda s: "B%dU%dG%dN%d%s" % (s[0], s[1], s[2], s[3], "".join("_" + k for k in sorted(s[5]))))
 def test_hip_matches_oracle_on_philox_streams(shape):
     """No injection: device Philox/Box-Muller vs the oracle's, construct + reset + steps + masked reset."""
     torch = _torch()
     from oracle import oracle as O
 
     B, U, G, N, T, over = shape
+    over = dict(over)
+    n_act = over.get("n_act", 5)
     groups = None
     if U % 4:
         groups = [U // 4] * 3 + [U - 3 * (U // 4)]
@@ -154,6 +163,7 @@ def test_hip_matches_oracle_on_philox_streams(shape):
         side = max(1, int(np.ceil(np.sqrt(B))))
         bs_init = [(G // (2 * side) + (b // side) * (G // side), G // (2 * side) + (b % side) * (G // side))
                    for b in range(B)]
+    bs_init = over.pop("bs_init", bs_init)
     seed, base = 0xC0FFEE1234, 1000
     env = _make(N, nBS=B, nUE=U, grid_n=G, groups=groups, bs_init=bs_init, seed=seed, env_id_base=base,
                 f64_outputs=True, **over)
@@ -174,10 +184,10 @@ def test_hip_matches_oracle_on_philox_streams(shape):
 
     compare("ctor")
     for t in range(T):
-        a = rs.randint(0, 5, size=(N, B)).astype(np.int64)
+        a = rs.randint(0, n_act, size=(N, B)).astype(np.int64)
         act = np.zeros(N, np.int64)
         for b in range(B):
-            act = act * 5 + a[:, b]
+            act = act * n_act + a[:, b]
         if t == T // 2:  # masked reset of every other env, as a caller would do on `done`
             mask = (np.arange(N) % 2).astype(np.uint8)
             env.reset(mask=mask)
