@@ -121,9 +121,11 @@ static int check_config(const UavEnvConfig &c) {
         }
     }
     if (c.max_step < 1 || c.bs_step < 0 || c.min_bs_dist < 0) return fail(UAVENV_E_INVALID, "config: bad step constants");
+    // Start cells must lie in [1, G-1]: the reference's boundaries are [1, G] (mobile_env.py:44-45) and cell G has no row in the
+    // G x G observation.  bs_move_serial() relies on this (its two-sided range test equals the reference's one-sided ones).
     for (int b = 0; b < c.n_bs; ++b)
-        if (c.bs_init_xy[b][0] < 0 || c.bs_init_xy[b][0] >= c.grid || c.bs_init_xy[b][1] < 0 || c.bs_init_xy[b][1] >= c.grid)
-            return fail(UAVENV_E_INVALID, "config: UAV start cell outside the grid");
+        if (c.bs_init_xy[b][0] < 1 || c.bs_init_xy[b][0] >= c.grid || c.bs_init_xy[b][1] < 1 || c.bs_init_xy[b][1] >= c.grid)
+            return fail(UAVENV_E_INVALID, "config: UAV start cell outside [1, grid-1]");
     return UAVENV_OK;
 }
 

@@ -257,6 +257,28 @@ __device__ __forceinline__ void uav_propose(const KParams &p, int xi, int yi, in
     else if (di == 8) { if (yi - sl > yMin) ny = yi - sl; }
 }
 
+// Displacement of digit d in units of BS_STEP, as (k + 2) in bits [3d, 3d+3): digits 0..3 = +x, -x, +y, -y by one step,
+// 4 stays, 5..8 the same four directions by two steps (ue_mobility.py:221-253).  check_config() keeps n_act <= 9, so d <= 8.
+constexpr uint32_t pack_digit_lut(int k0, int k1, int k2, int k3, int k4, int k5, int k6, int k7, int k8) {
+    return (uint32_t)(k0 + 2) | (uint32_t)(k1 + 2) << 3 | (uint32_t)(k2 + 2) << 6 | (uint32_t)(k3 + 2) << 9 | (uint32_t)(k4 + 2) << 12 |
+           (uint32_t)(k5 + 2) << 15 | (uint32_t)(k6 + 2) << 18 | (uint32_t)(k7 + 2) << 21 | (uint32_t)(k8 + 2) << 24;
+}
+constexpr uint32_t kDigitLutX = pack_digit_lut(+1, -1, 0, 0, 0, +2, -2, 0, 0);
+constexpr uint32_t kDigitLutY = pack_digit_lut(0, 0, +1, -1, 0, 0, 0, +2, -2);
+constexpr int digit_lut_k(uint32_t lut, int d) { return (int)((lut >> (3 * d)) & 7u) - 2; }
+// The tables against the compare/select formulation they replace (v1-v16 of this kernel), for every digit the config allows.
+constexpr int digit_dir(int d) { return d >= 5 ? d - 5 : d; }
+constexpr int digit_len(int d) { return (d == 4 || d > 8) ? 0 : (d >= 5 ? 2 : 1); }
+constexpr bool digit_luts_ok() {
+    for (int d = 0; d <= 8; ++d) {
+        const int kx = digit_dir(d) == 0 ? digit_len(d) : (digit_dir(d) == 1 ? -digit_len(d) : 0);
+        const int ky = digit_dir(d) == 2 ? digit_len(d) : (digit_dir(d) == 3 ? -digit_len(d) : 0);
+        if (digit_lut_k(kDigitLutX, d) != kx || digit_lut_k(kDigitLutY, d) != ky) return false;
+    }
+    return true;
+}
+static_assert(digit_luts_ok(), "digit -> displacement tables disagree with ue_mobility.py:221-253");
+
 // BS_move replayed serially in registers by EVERY lane for its own env (BT <= 8: B*(B-1) integer checks, no
 // cross-lane traffic).  profiles/r01_v8: the cooperative version (one UAV per lane, 3 ds_bpermute + 1 ballot per
 // sequential round, LDS staging + barrier) took 21 % of a wavefront's lifetime, more than twice the mobility tick.
@@ -266,7 +288,7 @@ template <int BT, bool FAST>
 __device__ __forceinline__ void bs_move_serial(const KParams &p, unsigned a, int (&bsx)[BT], int (&bsy)[BT]) {
     const int B = uav_count<BT, FAST>(p.B);
     const unsigned n = (unsigned)p.n_act;
-    const int xMin = 1, xMax = p.G, yMin = 1, yMax = p.G;      // mobile_env.py:45
+    const int xMin = 1, xMax = p.G;                            // mobile_env.py:45; the same bounds hold for y
     int dig[BT];
 #pragma unroll
     for (int b = BT - 1; b >= 0; --b) {                         // least significant digit -> UAV B-1
@@ -280,16 +302,19 @@ __device__ __forceinline__ void bs_move_serial(const KParams &p, unsigned a, int
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
         if (i < B) {
-            // proposal (:221-253), branch-free: digits 0..3 step BS_STEP, 5..8 step 2*BS_STEP, in +x, -x, +y, -y;
-            // 4 (and anything else) stays.  Only the moved coordinate is bounds-checked, as in the reference.
-            const int di = dig[i];
-            const int dir = (di >= 5) ? di - 5 : di;
-            const int step = (di == 4 || di > 8) ? 0 : ((di >= 5) ? 2 * p.bs_step : p.bs_step);
-            const int ddx = (dir == 0) ? step : ((dir == 1) ? -step : 0);
-            const int ddy = (dir == 2) ? step : ((dir == 3) ? -step : 0);
+            // proposal (:221-253), branch-free: one bit-field extract per axis instead of compare/select chains.
+            const uint32_t sh = 3u * (uint32_t)dig[i];
+            const int kx = (int)((kDigitLutX >> sh) & 7u) - 2, ky = (int)((kDigitLutY >> sh) & 7u) - 2;
+            const int ddx = kx * p.bs_step, ddy = ky * p.bs_step;
             const int nx = bsx[i] + ddx, ny = bsy[i] + ddy;
-            const int in_x = (ddx == 0) | ((nx > xMin) & (nx < xMax));
-            const int in_y = (ddy == 0) | ((ny > yMin) & (ny < yMax));
+            // Only the MOVED coordinate is range-checked, as in the reference (a UAV on a wall cell may slide along the wall), and
+            // at most one of (ddx, ddy) is non-zero; the grid is square (xMin == yMin, xMax == yMax, mobile_env.py:45), so one
+            // unsigned test xMin < moved < xMax does it.  The reference tests one side only (x + s < xMax, x - s > xMin); with
+            // start cells in [1, G-1] (check_config) and cells changing only through accepted moves, a + move lands on >= 2 and
+            // a - move on <= G-2, so the other side always holds and the two-sided test is the same predicate.  Digit 4 /
+            // bs_step == 0: nothing moves and the value of `inside` is irrelevant.
+            const int moved = (kx != 0) ? nx : ny;
+            const int inside = (int)((uint32_t)(moved - (xMin + 1)) < (uint32_t)(xMax - xMin - 1));
             // collision (:256-263): PRE-move cell of i against the current cells of all j != i; integer form of
             // norm <= min_dist, as a running minimum (one comparison, no chain of per-lane booleans)
             int dmin = 0x7FFFFFFF;
@@ -301,7 +326,7 @@ __device__ __forceinline__ void bs_move_serial(const KParams &p, unsigned a, int
                     dmin = d2 < dmin ? d2 : dmin;
                 }
             }
-            const int go = in_x & in_y & (int)(dmin > p.min_bs_dist2);               // :265-266
+            const int go = inside & (int)(dmin > p.min_bs_dist2);                     // :265-266
             bsx[i] += go * ddx;
             bsy[i] += go * ddy;
         }

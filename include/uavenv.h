@@ -41,7 +41,7 @@ enum {
 typedef struct UavEnvConfig {
     int32_t n_bs, n_ue, n_groups, grid;
     int32_t group_size[UAVENV_MAX_GROUPS]; /* walkers per RPGM group, sum == n_ue (mobile_env.py:76) */
-    int32_t bs_init_xy[UAVENV_MAX_BS][2];  /* UAV start cells (mobile_env.py:49-50)                  */
+    int32_t bs_init_xy[UAVENV_MAX_BS][2];  /* UAV start cells (mobile_env.py:49-50), each in [1, grid-1] */
     int32_t max_step;                      /* MAXSTEP = 2000                                          */
     int32_t bs_step;                       /* BS_STEP = 2                                             */
     int32_t min_bs_dist;                   /* MIN_BS_DIST + BS_STEP = 4 (mobile_env.py:157)           */
