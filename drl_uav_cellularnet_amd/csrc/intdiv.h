@@ -24,6 +24,12 @@ UAVENV_HD void u32div_gen(uint32_t d, uint32_t *magic, uint32_t *shift) {
     *shift = L;
 }
 
+// floor(lane / U) for lane in [0, 63] and U in [1, 64] is (lane * M) >> 16 with M = floor(65535 / U) + 1: M = 65536/U + delta,
+// 0 < delta <= 1, so the product overshoots lane/U by less than 64/65536 < 1/64 <= 1/U, the smallest gap to the next
+// integer.  lane * M < 2^24.  All 64 x 64 cases are checked in tests/native/lean_math_check.cpp.
+UAVENV_HD uint32_t lane_div_magic(uint32_t U) { return 65535u / U + 1u; }
+UAVENV_HD uint32_t lane_div(uint32_t lane, uint32_t magic) { return (lane * magic) >> 16; }
+
 UAVENV_HD uint32_t u32div(uint32_t a, uint32_t magic, uint32_t shift) {
     const uint32_t q = (uint32_t)(((uint64_t)a * magic) >> 32);
     const uint32_t t = ((a - q) >> 1) + q;

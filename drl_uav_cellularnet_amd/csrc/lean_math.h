@@ -155,11 +155,15 @@ UAVENV_HD double lm_logc(double x, const LeanCoef &c) {
     return dk * c.ln2_hi - ((hfsq - (s * (hfsq + R) + dk * c.ln2_lo)) - f);
 }
 
-// 1/sqrt(x), x finite, positive, normal.  Device: ocml rsqrt (v_rsq_f64 + one refinement, 10 VALU against 21+11 for
-// sqrt followed by a divide).  Host: the plain expression (used only by the accuracy test).
+// 1/sqrt(x), x finite, positive, normal.  Device: v_rsq_f64 + the refinement ocml's rsqrt applies (same operations in the
+// same order, so the same bits), without ocml's v_cmp_class guard that keeps a non-finite seed: for x = 0 (walker in the
+// UAV's own cell) this returns NaN where ocml returns inf, and rx_power() discards either through its d^2 > pl_dis^2 select.
+// Host: the plain expression (used only by the accuracy test).
 UAVENV_HD double lm_rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return rsqrt(x);
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = fma(y0 * -x, y0, 1.0);            // 1 - x*y0^2
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);        // y0 * (1 + e/2 + 3e^2/8)
 #else
     return 1.0 / sqrt(x);
 #endif

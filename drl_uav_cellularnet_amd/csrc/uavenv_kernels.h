@@ -347,7 +347,7 @@ __device__ __forceinline__ void walker_move(const HotConst &H, const LeanCoef &C
     // group centre; arctan2(0, 0) = 0 gives (1, 0).
     const double dxc = gx - x, dyc = gy - y;
     const double r2 = dxc * dxc + dyc * dyc;
-    const double rinv = lm_rsqrt(r2);         // r2 == 0 gives inf; the selects below discard it
+    const double rinv = lm_rsqrt(r2);         // r2 == 0 gives a non-finite value; the selects below discard it
     const double cc = (r2 > 0.0) ? dxc * rinv : 1.0;
     const double sc = (r2 > 0.0) ? dyc * rinv : 0.0;
     x = x + gv * gc;                          // :469 / :483
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
-                                                                              int Gr, int B_rt, const KParams p) {
+                                                                              int Gr, int B_rt, int lane_magic, const KParams p) {
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
     // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
     // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
@@ -603,8 +603,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = uav_count<BT, FAST>(B_rt);
     const StatePtrs st = state_from_blob(blob, N, U, B, Gr);
-    int slot = 0;
-    for (int s = 1; s < EPW; ++s) slot += (lane >= s * U) ? 1 : 0;
+    const int slot = (int)lane_div((uint32_t)lane, (uint32_t)lane_magic);   // lane / U (intdiv.h); lanes >= EPW*U are not live
     const int base = slot * U;   // first lane of my slot
     const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
     long long e = ((long long)blockIdx.x * kWavesPerBlock + wave) * EPW + slot;

@@ -79,6 +79,13 @@ int main() {
         }
         std::printf("lm_div %d %.4f %.4f\n", m, worst, sum / m);
     }
+    {   // csrc/intdiv.h: lane / U for every lane of a wavefront and every slot width
+        int bad = 0;
+        for (uint32_t U = 1; U <= 64; ++U)
+            for (uint32_t lane = 0; lane < 64; ++lane)
+                if (uavk::lane_div(lane, uavk::lane_div_magic(U)) != lane / U) ++bad;
+        std::printf("lane_div_mismatches 4096 %d 0\n", bad);
+    }
     run("rsqrt_dist2", [](double x) { return uavk::lm_rsqrt(x); }, [](long double x) { return 1.0L / std::sqrt(x); },
         [&](std::mt19937_64 &g) { return 25.0 * (double)(1 + g() % 2000000); }, n);
     // exact multiply-shift division used for the action digits: every divisor 2..9, dense + random + edge dividends
