@@ -133,6 +133,16 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
                              uavenv_t **out) {
     if (!cfg || !out || n_envs < 1) return fail(UAVENV_E_INVALID, "create: null argument or n_envs < 1");
     if (int rc = check_config(*cfg)) return rc;
+    {   // The kernels address state, outputs and actions as base + 32-bit byte offset (ldx/stx, uavenv_kernels.h): every array
+        // indexed that way must stay below 4 GiB.  Packed path (U <= 64, U >= B, U >= Gr): the widest row is U float64;
+        // multi-pass path: only the per-env scalars go through ldx/stx.  288 GB of HBM hold far larger batches: shard them
+        // over several handles (env_id_base keeps the Philox streams those of one big batch).
+        const bool packed = (cfg->n_ue <= 64) && (cfg->n_ue >= cfg->n_bs) && (cfg->n_ue >= cfg->n_groups);
+        const unsigned long long row = packed ? (unsigned long long)cfg->n_ue : 1ull;
+        if ((unsigned long long)n_envs * row * 8ull > 0xFFFFFFFFull)
+            return fail(UAVENV_E_INVALID, "create: n_envs too large for one handle (a state array would exceed 4 GiB); "
+                                          "shard the batch over several handles with env_id_base");
+    }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || device < 0 || device >= n_dev)
         return fail(UAVENV_E_NODEVICE, "create: no HIP device " + std::to_string(device));

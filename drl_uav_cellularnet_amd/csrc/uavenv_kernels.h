@@ -119,6 +119,31 @@ struct StatePtrs {
     int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
     unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
 };
+// Element access as  uniform base + 32-bit byte offset.  hipcc then emits the SGPR-base form
+// (global_load_dwordx2 v[..], v_off, s[base:base+1]) instead of one 64-bit VGPR address per array: arrays indexed alike share
+// ONE offset register, the per-array v_lshl_add_u64 / v_mad_u64_u32 address arithmetic disappears and half as many address
+// dwords go to the texture addresser per access.  Precondition, enforced by uavenv_create(): every array the packed kernel
+// indexes this way is smaller than 4 GiB, so idx * sizeof(T) cannot wrap.
+template <class T> __device__ __forceinline__ T ldx(const T *base, uint32_t idx) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + idx * (uint32_t)sizeof(T));
+}
+template <class T, class V> __device__ __forceinline__ void stx(T *base, uint32_t idx, V v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + idx * (uint32_t)sizeof(T)) = (T)v;
+}
+// An index for the stores of ONE basic block.  Without it hipcc hoists base + zext(offset) of a store into the kernel prologue
+// (v_lshl_add_u64 sgpr_base, vgpr_offset), keeps every such 64-bit address alive in a VGPR pair across the whole compute phase
+// and, selecting instructions block by block, can no longer fold it into the SGPR-base form at the store.  The empty asm
+// defines the index in the store's own block, so the address is formed there.  No instruction is emitted.
+// It is a trade, measured on one box (profiles/r01_v19_ab_addr32_*.txt): the SGPR-base form keeps ~29 base pointers alive in
+// SGPR pairs until the store phase.  In the variant that pins its constants in VGPRs (PIN, launches of <= 2 wavefronts per
+// SIMD) that costs 32 + 24 SGPR spill moves and is 1 % SLOWER than letting the compiler hoist (8.80 vs 8.71 us at 4096 envs);
+// in the unpinned variant it takes 106 -> 90 VGPRs, i.e. 5 instead of 4 wavefronts per SIMD, and is 3 % FASTER (53.7 vs 55.4 us
+// at 65536 envs).  Hence LOCAL = !PIN at the call sites.
+template <bool LOCAL> __device__ __forceinline__ uint32_t block_local(uint32_t idx) {
+    if (LOCAL) asm volatile("" : "+v"(idx));
+    return idx;
+}
+
 __device__ __forceinline__ StatePtrs state_from_blob(char *b, long long N, int U, int B, int Gr) {
     const StateOffsets L = compute_layout(N, U, B, Gr);
     StatePtrs s;
@@ -490,38 +515,38 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
 template <int MODE, bool FAST>
-__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, long long e, uint32_t tick, int agg, int deagg, int depth,
+__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, uint32_t e, uint32_t tick, int agg, int deagg, int depth,
                                            int step_n, double sum_cur, int n_outage) {
-    st.tick[e] = tick;
-    if (has_mobility(MODE)) { st.agg[e] = agg; st.deagg[e] = deagg; }
+    stx(st.tick, e, tick);
+    if (has_mobility(MODE)) { stx(st.agg, e, agg); stx(st.deagg, e, deagg); }
     if (is_reset(MODE)) {
-        st.fifo_depth[e] = 1;                                  // bestBS_buf = [current_BS] (channel.py:115)
-        st.step_n[e] = 0;                                      // mobile_env.py:146
+        stx(st.fifo_depth, e, 1);                              // bestBS_buf = [current_BS] (channel.py:115)
+        stx(st.step_n, e, 0);                                  // mobile_env.py:146
         const double mean = sum_cur * p.inv_U;
-        if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = 0;
-        if (UAV_OUT(p.out.reward)) p.out.reward[e] = 0.f;
-        if (UAV_OUT64(p.out.reward_f64)) p.out.reward_f64[e] = 0.0;
-        if (UAV_OUT(p.out.done)) p.out.done[e] = 0;
-        if (UAV_OUT(p.out.n_out)) p.out.n_out[e] = 0;
-        if (UAV_OUT(p.out.mean_sinr)) p.out.mean_sinr[e] = (float)mean;
-        if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
+        if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, 0);
+        if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, 0.f);
+        if (UAV_OUT64(p.out.reward_f64)) stx(p.out.reward_f64, e, 0.0);
+        if (UAV_OUT(p.out.done)) stx(p.out.done, e, 0);
+        if (UAV_OUT(p.out.n_out)) stx(p.out.n_out, e, 0);
+        if (UAV_OUT(p.out.mean_sinr)) stx(p.out.mean_sinr, e, (float)mean);
+        if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
     }
     if (is_step(MODE)) {
-        if (depth < 3) st.fifo_depth[e] = depth + 1;
+        if (depth < 3) stx(st.fifo_depth, e, depth + 1);
         const double mean = sum_cur * p.inv_U;                // channel.py:216 (np.mean; <= 1 ulp from sum/U)
         const double r0 = sum_cur * p.inv_U20;                // mobile_env.py:165  mean / 20
         const double r1 = -((double)n_outage * p.inv_U);      // mobile_env.py:167  -1.0 * nOut / nUE
         double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
-        st.step_n[e] = step_n;
-        if (UAV_OUT(p.out.step_n)) p.out.step_n[e] = step_n;
-        if (UAV_OUT(p.out.done)) p.out.done[e] = (uint8_t)(step_n >= p.max_step);
-        if (UAV_OUT(p.out.reward)) p.out.reward[e] = (float)reward;
-        if (UAV_OUT64(p.out.reward_f64)) p.out.reward_f64[e] = reward;
-        if (UAV_OUT(p.out.mean_sinr)) p.out.mean_sinr[e] = (float)mean;
-        if (UAV_OUT64(p.out.mean_sinr_f64)) p.out.mean_sinr_f64[e] = mean;
-        if (UAV_OUT(p.out.n_out)) p.out.n_out[e] = n_outage;
+        stx(st.step_n, e, step_n);
+        if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, step_n);
+        if (UAV_OUT(p.out.done)) stx(p.out.done, e, (uint8_t)(step_n >= p.max_step));
+        if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, (float)reward);
+        if (UAV_OUT64(p.out.reward_f64)) stx(p.out.reward_f64, e, reward);
+        if (UAV_OUT(p.out.mean_sinr)) stx(p.out.mean_sinr, e, (float)mean);
+        if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
+        if (UAV_OUT(p.out.n_out)) stx(p.out.n_out, e, n_outage);
     }
 }
 
@@ -616,6 +641,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
     const long long iu = e * U + (live ? u : 0);
+    // 32-bit element indices for ldx()/stx(): env, walker [N,U], group [N,Gr], UAV [N,B], FIFO row 0 [N,3,U]
+    const uint32_t e32 = (uint32_t)e, iu32 = (uint32_t)iu;
+    const uint32_t ig32 = e32 * (uint32_t)Gr + (uint32_t)ul, ib32 = e32 * (uint32_t)B + (uint32_t)ul;
+    const uint32_t if32 = e32 * 3u * (uint32_t)U + (uint32_t)u;
     const bool head = live && (ul == 0);                             // writes the per-env scalars
     const bool bown = (MODE != MODE_WARMUP) && live && (ul < B);     // this lane owns UAV `ul`
     const bool gown = (has_mobility(MODE)) && live && (ul < Gr);     // this lane owns RPGM group `ul`
@@ -630,33 +659,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     for (int b = 0; b < BT; ++b) { bsx[b] = 0; bsy[b] = 0; }
     if (MODE != MODE_WARMUP) {
         if (REG_MOVE) {
-            const int2 *cells = reinterpret_cast<const int2 *>(is_reset(MODE) ? p.bs_init : st.bs_xy + e * B * 2);
+            const int2 *cells = reinterpret_cast<const int2 *>(is_reset(MODE) ? p.bs_init : st.bs_xy);
+            const uint32_t c0 = is_reset(MODE) ? 0u : e32 * (uint32_t)B;                 // mobile_env.py:119 on reset
 #pragma unroll
             for (int b = 0; b < BT; ++b)
-                if (b < B) { const int2 q = cells[b]; bsx[b] = q.x; bsy[b] = q.y; }   // mobile_env.py:119 on reset
-            if (is_step(MODE)) act = actions[e];
+                if (b < B) { const int2 q = ldx(cells, c0 + (uint32_t)b); bsx[b] = q.x; bsy[b] = q.y; }
+            if (is_step(MODE)) act = ldx(actions, e32);
         } else if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }
-            else { bx = st.bs_xy[(e * B + ul) * 2]; by = st.bs_xy[(e * B + ul) * 2 + 1]; }
-            if (is_step(MODE)) { act = actions[e]; apw = p.act_pow[ul]; }
+            else { const int2 q = ldx(reinterpret_cast<const int2 *>(st.bs_xy), ib32); bx = q.x; by = q.y; }
+            if (is_step(MODE)) { act = ldx(actions, e32); apw = p.act_pow[ul]; }
         }
     }
-    uint32_t tick = st.tick[e];
+    uint32_t tick = ldx(st.tick, e32);
     int agg = 0, deagg = 0;
-    if (has_mobility(MODE)) { agg = st.agg[e]; deagg = st.deagg[e]; }
+    if (has_mobility(MODE)) { agg = ldx(st.agg, e32); deagg = ldx(st.deagg, e32); }
     int depth = 0, step_n = 0;
-    if (is_step(MODE)) { depth = st.fifo_depth[e]; step_n = st.step_n[e]; }
+    if (is_step(MODE)) { depth = ldx(st.fifo_depth, e32); step_n = ldx(st.step_n, e32); }
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
-        ogx = st.g_x[e * Gr + ul]; ogy = st.g_y[e * Gr + ul]; ogfl = st.g_fl[e * Gr + ul];
-        ogv = st.g_v[e * Gr + ul]; ogc = st.g_cos[e * Gr + ul]; ogs = st.g_sin[e * Gr + ul];
+        ogx = ldx(st.g_x, ig32); ogy = ldx(st.g_y, ig32); ogfl = ldx(st.g_fl, ig32);
+        ogv = ldx(st.g_v, ig32); ogc = ldx(st.g_cos, ig32); ogs = ldx(st.g_sin, ig32);
     }
     double x = 0, y = 0, hu = 0, hu_inj = 0;
     int ix = 0, iy = 0, gid = 0;
     if (has_mobility(MODE)) {
-        gid = gid_of_u[u];                                         // table padded to >= 64 entries: dead lanes have u < 64
+        gid = ldx(gid_of_u, (uint32_t)u);                          // table padded to >= 64 entries: dead lanes have u < 64
         if (live) {
-            x = st.ue_x[iu]; y = st.ue_y[iu]; hu = st.ue_hu[iu];
+            x = ldx(st.ue_x, iu32); y = ldx(st.ue_y, iu32); hu = ldx(st.ue_hu, iu32);
             if (UAV_INJ(p.inj_theta)) hu_inj = p.inj_theta[iu];   // injected draws cover exactly one tick
         }
     } else if (live) {                                            // mobile_env.py:202-203 (read_trace)
@@ -666,10 +696,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     unsigned long long prev_out = 0ull;
     if (is_step(MODE)) {
         if (live) {
-            serving = st.serving[iu];
-            r0 = st.fifo[(e * 3 + 0) * U + u]; r1 = st.fifo[(e * 3 + 1) * U + u]; r2 = st.fifo[(e * 3 + 2) * U + u];
+            serving = ldx(st.serving, iu32);
+            r0 = ldx(st.fifo, if32); r1 = ldx(st.fifo, if32 + (uint32_t)U); r2 = ldx(st.fifo, if32 + 2u * (uint32_t)U);
         }
-        prev_out = st.out_bits[e];
+        prev_out = ldx(st.out_bits, e32);                          // one 64-bit word per env here (U <= 64)
     }
 
     // Only now touch the parameter struct: its (cold) kernarg fetch overlaps the global loads issued above.
@@ -788,29 +818,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
 
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
-        if (has_mobility(MODE)) { st.ue_x[iu] = x; st.ue_y[iu] = y; st.ue_hu[iu] = hu; }
-        st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
+        const uint32_t iw = block_local<!PIN>(iu32), fw = block_local<!PIN>(if32);
+        if (has_mobility(MODE)) { stx(st.ue_x, iw, x); stx(st.ue_y, iw, y); stx(st.ue_hu, iw, hu); }
+        stx(st.ue_xy, 2u * iw, (int16_t)ix); stx(st.ue_xy, 2u * iw + 1u, (int16_t)iy);
         if (MODE != MODE_WARMUP) {
-            st.serving[iu] = (int8_t)serving;
-            st.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-            if (!is_reset(MODE)) { st.fifo[(e * 3 + 1) * U + u] = (int8_t)r1; st.fifo[(e * 3 + 2) * U + u] = (int8_t)r2; }
-            if (UAV_OUT(p.out.ue_xy)) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
-            if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
-            if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
-            if (UAV_OUT64(p.out.cur_sinr_f64)) p.out.cur_sinr_f64[iu] = cur;
+            stx(st.serving, iw, (int8_t)serving);
+            stx(st.fifo, fw, (int8_t)r0);
+            if (!is_reset(MODE)) { stx(st.fifo, fw + (uint32_t)U, (int8_t)r1); stx(st.fifo, fw + 2u * (uint32_t)U, (int8_t)r2); }
+            if (UAV_OUT(p.out.ue_xy)) { stx(p.out.ue_xy, 2u * iw, (int16_t)ix); stx(p.out.ue_xy, 2u * iw + 1u, (int16_t)iy); }
+            if (UAV_OUT(p.out.serving)) stx(p.out.serving, iw, (int8_t)serving);
+            if (UAV_OUT(p.out.cur_sinr)) stx(p.out.cur_sinr, iw, (float)cur);
+            if (UAV_OUT64(p.out.cur_sinr_f64)) stx(p.out.cur_sinr_f64, iw, cur);
         }
     }
     if (gown) {
-        st.g_x[e * Gr + ul] = ogx; st.g_y[e * Gr + ul] = ogy; st.g_fl[e * Gr + ul] = ogfl;
-        st.g_v[e * Gr + ul] = ogv; st.g_cos[e * Gr + ul] = ogc; st.g_sin[e * Gr + ul] = ogs;
+        const uint32_t gw = block_local<!PIN>(ig32);
+        stx(st.g_x, gw, ogx); stx(st.g_y, gw, ogy); stx(st.g_fl, gw, ogfl);
+        stx(st.g_v, gw, ogv); stx(st.g_cos, gw, ogc); stx(st.g_sin, gw, ogs);
     }
     if (bown) {
-        st.bs_xy[(e * B + ul) * 2] = bx; st.bs_xy[(e * B + ul) * 2 + 1] = by;
-        if (UAV_OUT(p.out.bs_xy)) { p.out.bs_xy[(e * B + ul) * 2] = bx; p.out.bs_xy[(e * B + ul) * 2 + 1] = by; }
+        const uint32_t bw = block_local<!PIN>(ib32);
+        stx(st.bs_xy, 2u * bw, bx); stx(st.bs_xy, 2u * bw + 1u, by);
+        if (UAV_OUT(p.out.bs_xy)) { stx(p.out.bs_xy, 2u * bw, bx); stx(p.out.bs_xy, 2u * bw + 1u, by); }
     }
     if (head) {
-        if (MODE != MODE_WARMUP) st.out_bits[e] = ob;                                     // :116 / :173
-        env_finish<MODE, FAST>(p, st, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        const uint32_t ew = block_local<!PIN>(e32);
+        if (MODE != MODE_WARMUP) stx(st.out_bits, ew, ob);                                // :116 / :173
+        env_finish<MODE, FAST>(p, st, ew, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -996,7 +1030,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         }
         tick += 1u;
     }
-    if (lane == 0) env_finish<MODE, FAST>(p, st, e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (lane == 0) env_finish<MODE, FAST>(p, st, (uint32_t)e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
 // ================================================================================================

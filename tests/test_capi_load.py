@@ -41,6 +41,32 @@ def test_host_side_calls_without_gpu():
     assert b"default_config" in lib.uavenv_last_error()
 
 
+def test_create_validates_before_touching_the_device():
+    """uavenv_create() refuses, before any HIP call, what the kernels cannot handle: a batch whose arrays would pass 4 GiB
+    (they are addressed as base + 32-bit byte offset) and UAV start cells outside [1, grid-1] (the reference's boundaries)."""
+    import torch
+
+    from drl_uav_cellularnet_amd import _capi
+
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    cfg = _capi.make_config(4, 20, 100)
+    limit = 0xFFFFFFFF // (20 * 8)                      # packed path: widest row = 20 float64
+    assert lib.uavenv_create(ctypes.byref(cfg), limit + 1, 0, 1, 0, ctypes.byref(h)) == -1
+    assert b"too large" in lib.uavenv_last_error() and not h.value
+    if not torch.cuda.is_available():                    # exactly at the limit the size check passes; here the next check fails
+        assert lib.uavenv_create(ctypes.byref(cfg), limit, 0, 1, 0, ctypes.byref(h)) != 0
+        assert b"too large" not in lib.uavenv_last_error() and b"HIP device" in lib.uavenv_last_error()
+    big = _capi.make_config(16, 200, 100, bs_init=[(5 + 6 * b, 50) for b in range(16)])   # multi-pass: only N * 8 is bounded
+    assert lib.uavenv_create(ctypes.byref(big), 0xFFFFFFFF // 8 + 1, 0, 1, 0, ctypes.byref(h)) == -1
+    assert b"too large" in lib.uavenv_last_error()
+    for cell in ((0, 50), (50, 0), (100, 50), (50, 100), (-1, 50)):
+        bad = _capi.make_config(4, 20, 100)
+        bad.bs_init_xy[2][0], bad.bs_init_xy[2][1] = cell
+        assert lib.uavenv_create(ctypes.byref(bad), 8, 0, 1, 0, ctypes.byref(h)) == -1, cell
+        assert b"start cell" in lib.uavenv_last_error()
+
+
 def test_struct_sizes_match_oracle_layout():
     # the oracle mirrors the config struct field for field; a drift would silently skew parity runs
     from drl_uav_cellularnet_amd import _capi
