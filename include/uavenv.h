@@ -108,7 +108,11 @@ const char *uavenv_last_error(void);
 /* Reference constants for (n_bs, n_ue, grid); 4 equal groups; the 4-UAV layout when n_bs == 4. */
 int uavenv_default_config(UavEnvConfig *cfg, int n_bs, int n_ue, int grid);
 
-/* Allocate N envs on `device`.  env_id_base offsets the Philox env id (rank * N for sharding). */
+/* Allocate N envs on `device`.  env_id_base offsets the Philox env id (rank * N for sharding).
+ * UAVENV_E_INVALID (see uavenv_last_error) for a config check_config rejects, and for a batch too large for ONE handle: the
+ * kernels address each state / output array as base + 32-bit byte offset, so n_envs * n_ue * 8 must stay below 4 GiB when
+ * n_ue <= 64 (26.8 M envs at n_ue = 20), and n_envs * 8 otherwise.  Larger batches: several handles with consecutive
+ * env_id_base ranges, which are bit-identical to one big batch. */
 int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device, uint64_t seed, uint32_t env_id_base,
                   uavenv_t **out);
 void uavenv_destroy(uavenv_t *h);
