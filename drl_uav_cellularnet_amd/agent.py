@@ -39,6 +39,24 @@ def obs_to_indices(obs, grid_n, n_bs):
     return torch.cat([bs_idx, ue_idx], dim=-1)          # [N, B + U]; duplicates add, like the count map
 
 
+def first_layer_reference(idx, w_a, b_a, w_c=None, b_c=None):
+    """The sparse first layer in plain PyTorch: (h_a, h_c), h = sum_k W[idx[:, k]] + b.  Reference implementation of the HIP
+    kernel (tests/test_agent_kernel_gpu.py) and the path CPU tensors take."""
+    ha = F.embedding_bag(idx, w_a, mode="sum") + b_a
+    hc = None if w_c is None else F.embedding_bag(idx, w_c, mode="sum") + b_c
+    return ha, hc
+
+
+def sparse_first_layer(idx, w_a, b_a, w_c=None, b_c=None):
+    """x @ W + b of main.py:147-148,153 for the raveled state with its nBS + nUE non-zero entries given as row indices.
+    CUDA tensors: one launch of libuavagent.so for both tables (they share idx), an error if the library is missing."""
+    if idx.is_cuda:
+        from ._agent_capi import sparse_first_layer_cuda
+
+        return sparse_first_layer_cuda(idx, w_a, b_a, w_c, b_c)
+    return first_layer_reference(idx, w_a, b_a, w_c, b_c)
+
+
 class ACNet(torch.nn.Module):
     """Actor and critic trunks of main.py:143-156.  The first layers are stored as [N_S, 200] tables so that the
     sparse path is an embedding-bag sum; ``forward_dense`` is the textbook matmul on the raveled dense state."""
@@ -73,17 +91,16 @@ class ACNet(torch.nn.Module):
 
     def forward(self, idx):
         """idx: int64 [M, K] flat indices of the non-zero cells (obs_to_indices)."""
-        ha = F.embedding_bag(idx, self.a_w1, mode="sum") + self.a_b1
-        hc = F.embedding_bag(idx, self.c_w1, mode="sum") + self.c_b1
+        ha, hc = sparse_first_layer(idx, self.a_w1, self.a_b1, self.c_w1, self.c_b1)
         return self._heads(ha, hc)
 
     def actor_only(self, idx):
-        ha = F.embedding_bag(idx, self.a_w1, mode="sum") + self.a_b1
+        ha, _ = sparse_first_layer(idx, self.a_w1, self.a_b1)
         ha = F.relu6(F.relu6(ha) @ self.a_w2 + self.a_b2)
         return torch.softmax(ha @ self.a_w3 + self.a_b3, dim=-1)
 
     def critic_only(self, idx):
-        hc = F.embedding_bag(idx, self.c_w1, mode="sum") + self.c_b1
+        hc, _ = sparse_first_layer(idx, self.c_w1, self.c_b1)
         hc = F.relu6(F.relu6(hc) @ self.c_w2 + self.c_b2)
         return hc @ self.c_w3 + self.c_b3
 
@@ -165,6 +182,16 @@ def allreduce_mean_grads(params):
     return n
 
 
+def sample_actions(prob, generator=None):
+    """One action per row of ``prob`` [N, n_action], the way the reference draws it (main.py:167-168):
+    np.random.choice(range(n), p=p) is cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, uniform, side='right').
+    Same three steps on the device (one uniform per env from ``generator``); a third of the time of torch.multinomial at
+    [8192, 625] (tools/profile_a2c.py).  An action of probability 0 is never drawn; the result is always < n_action."""
+    cdf = prob.cumsum(dim=1)
+    u = torch.rand((prob.shape[0], 1), device=prob.device, dtype=prob.dtype, generator=generator) * cdf[:, -1:]
+    return torch.searchsorted(cdf, u, right=True).squeeze(1).clamp_(max=prob.shape[1] - 1)
+
+
 class A2CRunner:
     """Synchronous A2C over a BatchedMobiEnv: every env instance plays the role of one of the reference's workers
     (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step."""
@@ -196,7 +223,7 @@ class A2CRunner:
         done = None
         for t in range(T):
             prob = self.net.actor_only(self.idx)                                     # choose_action, main.py:165-169
-            a = torch.multinomial(prob, 1, generator=self.gen).squeeze(1)
+            a = sample_actions(prob, self.gen)
             idx_buf[t], act_buf[t] = self.idx, a
             obs, reward, done, _ = env.step(a)
             rew_buf[t] = reward

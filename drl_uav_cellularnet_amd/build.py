@@ -1,4 +1,4 @@
-"""Builds libuavenv.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+"""Builds libuavenv.so (env kernels + C ABI) and libuavagent.so (the learner's sparse first layer) for gfx950 with hipcc, in-tree.
 
 ``python -m drl_uav_cellularnet_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles
 without a GPU; the built library is git-ignored but travels to the GPU box with the tree.
@@ -16,6 +16,9 @@ DEPS = [SRC] + [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "
     os.path.join(ROOT, "include", "uavenv.h")]
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libuavenv.so")
+AGENT_SRC = os.path.join(PKG_DIR, "csrc", "agent_kernels.hip")
+AGENT_DEPS = [AGENT_SRC, os.path.join(ROOT, "include", "uavagent.h")]
+AGENT_LIB = os.path.join(LIB_DIR, "libuavagent.so")
 ARCH = "gfx950"
 
 
@@ -26,14 +29,31 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def needs_build():
-    if not os.path.isfile(LIB):
+def _stale(lib, deps):
+    if not os.path.isfile(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, DEPS)
+
+
+def build_agent(force=False, verbose=False):
+    """libuavagent.so (include/uavagent.h): used by agent.py for CUDA tensors; the env library does not depend on it."""
+    if not force and not _stale(AGENT_LIB, AGENT_DEPS):
+        return AGENT_LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-Wall", "-o", AGENT_LIB, AGENT_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return AGENT_LIB
 
 
 def build(force=False, verbose=False, extra_flags=()):
+    build_agent(force=force, verbose=verbose)
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)

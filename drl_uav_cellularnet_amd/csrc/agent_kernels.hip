@@ -1,0 +1,120 @@
+// libuavagent.so: the sparse first layer of the actor / critic trunks (main.py:143-156 on the raveled state of main.py:190) for gfx950.
+// Interface and rationale: include/uavagent.h.  Reference implementation and CPU path: agent.py (F.embedding_bag + bias).
+//
+// One wavefront per sample.  Lane k < K fetches index k of its sample (one coalesced load); v_readlane turns each index into a
+// SCALAR row base, so every row read is  global_load_dwordx4 v, v_lane_offset, s[row]  (SGPR-base form, no per-lane 64-bit
+// address arithmetic).  Lanes 0 .. H/4-1 own one float4 column group each: a 200-float row is 50 lanes x 16 B, 7 cache lines.
+// The tables (N_S x H x 4 B = 40 MB each at the reference's sizes) stay resident in L2 / Infinity Cache, so the kernel is
+// bound by cache bandwidth and load latency, not HBM: rows are read in groups of UNR (x2 tables) so that many reads are in flight.
+// Sum order: k ascending in fp32, bias last -- embedding_bag(idx, W, mode="sum") + b.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/uavagent.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+__device__ __forceinline__ void add4(float4 &s, const float4 &v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+
+// KT > 0: K known at compile time (24 = 4 UAV + 20 UE, 44 = 4 + 40), so the row loop unrolls by UNR with no remainder --
+// v_readlane is a convergent operation and hipcc will not unroll a loop around it when the trip count is a run-time value.
+// KT == 0: any K, one row (per table) in flight at a time.
+template <bool TWO, int KT, int UNR>
+__global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__restrict__ wa, const float *__restrict__ ba,
+                                                              float *__restrict__ oa, const float *__restrict__ wc,
+                                                              const float *__restrict__ bc, float *__restrict__ oc,
+                                                              const long long *__restrict__ idx, long long M, int K_rt, int H4,
+                                                              long long n_rows) {
+    static_assert(KT == 0 || KT % UNR == 0, "the row groups must tile K exactly");
+    const int K = KT > 0 ? KT : K_rt;
+    const int lane = threadIdx.x & 63;
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // the same for all lanes of a wavefront
+    if (m >= M) return;
+    long long mine = 0;
+    if (lane < K) mine = idx[m * K + lane];
+    // Memory safety on a shared GPU: an index outside the table is clamped, never dereferenced (include/uavagent.h).
+    mine = mine < 0 ? 0 : (mine >= n_rows ? n_rows - 1 : mine);
+    const uint32_t row_bytes = (uint32_t)H4 * 16u;
+    const uint32_t my_row_off = (uint32_t)mine * row_bytes;          // < 4 GiB: checked by the host entry point
+    // Every lane loads UNCONDITIONALLY: a conditional float4 load is split by hipcc into four exec-masked dword loads with a
+    // vmcnt(0) wait after each.  Lanes >= H4 re-read the last column group (an in-range address); their sums are never stored.
+    const bool on = lane < H4;
+    const uint32_t lane_off = (uint32_t)(on ? lane : H4 - 1) * 16u;
+    float4 sa = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+    if (KT > 0) {
+        // The outer loop stays a loop: fully unrolled, the scheduler hoists all 2*KT row reads to the top (156 VGPRs at KT = 24,
+        // 258 at KT = 44).  UNR reads per table in flight is the intent; KT % UNR == 0, so there is no remainder.
+#pragma unroll 1
+        for (int k0 = 0; k0 < KT; k0 += UNR) {
+            float4 va[UNR], vc[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {                            // UNR (x2 tables) row reads in flight
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, k0 + j) + lane_off;
+                va[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wa) + off);
+                if (TWO) vc[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wc) + off);
+            }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { add4(sa, va[j]); if (TWO) add4(sc, vc[j]); }   // k ascending
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, k) + lane_off;
+            add4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wa) + off));
+            if (TWO) add4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wc) + off));
+        }
+    }
+    if (!on) return;
+    const unsigned long long o = (unsigned long long)m * row_bytes;
+    if (ba != nullptr) add4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ba) + lane_off));
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(oa) + o + lane_off) = sa;
+    if (TWO) {
+        if (bc != nullptr) add4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(bc) + lane_off));
+        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(oc) + o + lane_off) = sc;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int uavagent_abi_version(void) { return 1; }
+extern "C" const char *uavagent_last_error(void) { return g_err.c_str(); }
+
+extern "C" int uavagent_sparse_rows_sum_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
+                                            const float *bias_c, float *out_c, const int64_t *idx, int64_t m_rows, int32_t k,
+                                            int32_t h, int64_t n_rows, void *stream) {
+    if (m_rows < 0 || n_rows < 1 || k < 1 || k > 64) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: need m_rows >= 0, n_rows >= 1, 1 <= k <= 64");
+    if (h < 4 || h > 256 || (h & 3)) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: h must be a multiple of 4 in [4, 256]");
+    if ((unsigned long long)n_rows * (unsigned long long)h * 4ull > 0xFFFFFFFFull)
+        return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: a table must be smaller than 4 GiB (rows are addressed by 32-bit byte offsets)");
+    if (m_rows == 0) return UAVAGENT_OK;      // an empty batch: idx and the outputs may legitimately be null (torch's empty tensors are)
+    if ((w_c != nullptr) != (out_c != nullptr)) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: w_c and out_c go together");
+    if (!w_a || !out_a || !idx) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: null table, output or index pointer");
+    if (!aligned16(w_a) || !aligned16(out_a) || !aligned16(w_c) || !aligned16(out_c) || !aligned16(bias_a) || !aligned16(bias_c))
+        return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: tables, biases and outputs must be 16-byte aligned");
+    const long long blocks = (m_rows + 3) / 4;
+    if (blocks > 0x7FFFFFFFll) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: m_rows too large for one launch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long *ix = reinterpret_cast<const long long *>(idx);
+#define UAVAGENT_LAUNCH(TWO_, KT_, UNR_)                                                                                  \
+    hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a, out_a, \
+                       w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows)
+    if (w_c) {
+        if (k == 24) UAVAGENT_LAUNCH(true, 24, 8);
+        else if (k == 44) UAVAGENT_LAUNCH(true, 44, 4);
+        else UAVAGENT_LAUNCH(true, 0, 1);
+    } else {
+        if (k == 24) UAVAGENT_LAUNCH(false, 24, 8);
+        else if (k == 44) UAVAGENT_LAUNCH(false, 44, 4);
+        else UAVAGENT_LAUNCH(false, 0, 1);
+    }
+#undef UAVAGENT_LAUNCH
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(UAVAGENT_E_HIP, std::string("sparse_rows_sum launch: ") + hipGetErrorString(e));
+    return UAVAGENT_OK;
+}

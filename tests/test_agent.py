@@ -217,3 +217,31 @@ def test_gradient_heuristic_side_means():
     np.testing.assert_allclose(m, [20.0, np.mean([10.0, -5.0, 1.0]), np.mean([-5.0, 1.0]), np.mean([10.0, 20.0])])
     m = side_means(sinr, ue, np.array([9, 0, 10]))                     # nobody has x > 9 or y <= 0 ... y<=0: none
     assert np.isnan(m[0]) and not np.isnan(m[1]) and int(np.nanargmin(m)) in (1, 2, 3)
+
+
+def test_sample_actions_is_an_inverse_cdf_draw():
+    """agent.sample_actions against np.random.choice's algorithm (main.py:167-168): zero-probability actions are never drawn,
+    frequencies follow p, the draw is a pure function of (prob, generator state)."""
+    from drl_uav_cellularnet_amd.agent import sample_actions
+
+    p = torch.tensor([[0.0, 0.5, 0.0, 0.25, 0.25, 0.0],        # zeros at both ends and inside
+                      [1.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+                      [0.0, 0.0, 0.0, 0.0, 0.0, 1.0],
+                      [0.1, 0.1, 0.2, 0.3, 0.2, 0.1]])
+    n = 40000
+    g = torch.Generator().manual_seed(5)
+    draws = sample_actions(p.repeat(n, 1), g).reshape(n, 4)
+    assert draws.dtype == torch.int64 and int(draws.min()) >= 0 and int(draws.max()) <= 5
+    freq = torch.stack([(draws == a).float().mean(dim=0) for a in range(6)], dim=1)     # [4 rows of p, 6 actions]
+    assert torch.all(freq[p == 0] == 0)
+    assert torch.allclose(freq, p, atol=0.01)
+    g2 = torch.Generator().manual_seed(5)
+    assert torch.equal(sample_actions(p.repeat(n, 1), g2).reshape(n, 4), draws)
+    # the same uniforms through numpy's own steps
+    g3 = torch.Generator().manual_seed(11)
+    q = torch.softmax(torch.randn(64, 625, generator=torch.Generator().manual_seed(1)), dim=1)
+    mine = sample_actions(q, g3)
+    u = torch.rand((64, 1), generator=torch.Generator().manual_seed(11))
+    cdf = np.cumsum(q.numpy(), axis=1)
+    want = [int(np.searchsorted(cdf[i], float(u[i, 0]) * cdf[i, -1], side="right")) for i in range(64)]
+    assert mine.tolist() == [min(w, 624) for w in want]

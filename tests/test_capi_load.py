@@ -26,6 +26,28 @@ def test_header_symbols_are_exported():
     assert set(names) == set(_capi.EXPORTS)
 
 
+def test_agent_library_exports_its_header():
+    """libuavagent.so (include/uavagent.h, the learner's sparse first layer): built, loadable, every declared symbol exported;
+    argument checks answer before any HIP call."""
+    from drl_uav_cellularnet_amd import _agent_capi, build
+
+    build.build_agent()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "uavagent.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(uavagent_[a-z0-9_]+)\s*\(", text)))
+    lib = _agent_capi.load()
+    assert set(names) == set(_agent_capi.EXPORTS) and all(hasattr(lib, n) for n in names)
+    assert lib.uavagent_abi_version() == 1
+    assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 1, 24, 200, 100, None) == -1
+    assert b"null" in lib.uavagent_last_error()
+    assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 0, 24, 200, 100, None) == 0   # empty batch
+    one = ctypes.c_void_p(16)                               # a non-null, 16-byte aligned dummy: never dereferenced on these paths
+    assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 1, 24, 202, 100, None) == -1
+    assert b"multiple of 4" in lib.uavagent_last_error()
+    assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 1, 24, 200, 2 ** 40, None) == -1
+    assert b"4 GiB" in lib.uavagent_last_error()
+    assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 0, 24, 200, 100, None) == 0   # m_rows = 0: no launch
+
+
 def test_host_side_calls_without_gpu():
     from drl_uav_cellularnet_amd import _capi
 
