@@ -31,6 +31,15 @@ def algorithmic_bytes_per_env_step(U, B, Gr):
     return 48 * U + 2 * ((U + 7) // 8) + 96 * Gr + 16 * B + 45
 
 
+def transcendental_evals_per_env_step(U, B):
+    """SURVEY.md section 8(d) asks for the achieved transcendental rate beside the HBM figure (the kernel is issue-bound, not
+    bandwidth-bound).  Float64 function evaluations per walker and step in csrc/uavenv_kernels.h, HB = ceil(B/2) Box-Muller pairs:
+    sincospi 1 (heading) + HB;  log HB (Box-Muller) + 2 (SINR of the best and of the serving UAV);
+    rsqrt 1 (pull towards the group centre) + HB (Box-Muller radius) + B (d^-3);  exp2 B (shadowing)  =  4 + 3*HB + 2*B."""
+    hb = (B + 1) // 2
+    return U * (4 + 3 * hb + 2 * B)
+
+
 STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true>"   # rocprofv3 name (template part) of the step kernel of this workload
 
 
@@ -178,7 +187,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(E) if baseline_shape else None,
                          "kernel": STEP_KERNEL if baseline_shape else "env kernel of this shape (secondary measurement)", "algorithmic_bytes_per_launch": b_step * E,
-                         "avg_launch_us": per_launch_s * 1e6},
+                         "avg_launch_us": per_launch_s * 1e6,
+                         "transcendental_evals_per_launch": transcendental_evals_per_env_step(n_ue, n_bs) * E,
+                         "transcendental_evals_per_s": transcendental_evals_per_env_step(n_ue, n_bs) * E / per_launch_s},
         }
         if world == 1 and not args.no_cpu_baseline and baseline_shape:
             line["cpu_baseline"] = cpu_baseline()
