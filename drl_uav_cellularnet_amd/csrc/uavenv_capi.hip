@@ -322,8 +322,11 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     }
     constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
     const bool fast = call_is_fast(p) && (p.B == h->bt);   // FAST kernels are compiled for B == BT exactly
-    // PIN variant (constants pinned in VGPRs, occupancy 2) only when the launch needs <= 2 wavefronts per SIMD
-    bool pin = fast && (waves <= 2 * h->n_simd);
+    // PIN variant (constants pinned in VGPRs, occupancy 2) only when the launch puts between one and two wavefronts on a SIMD.
+    // Sweep on one box, pinned vs unpinned (profiles/r01_v19_pin_sweep.txt): 0.67 waves/SIMD 7.50 vs 7.23 us, 1.0 tie, 1.33
+    // 8.67 vs 9.20, 2.0 9.29 vs 9.77, 2.67 12.87 vs 12.08, 4.0 15.87 vs 14.98: two co-resident waves profit from constants that
+    // are not re-read through the scalar path; a lone wave only pays for materialising them; beyond two, occupancy wins.
+    bool pin = fast && (waves >= h->n_simd) && (waves <= 2 * h->n_simd);
     if (const char *f = std::getenv("UAVENV_FORCE_PIN")) pin = fast && (f[0] == '1');   // experiments only
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
