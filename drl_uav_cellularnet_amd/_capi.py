@@ -42,8 +42,7 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
-STATE_FIELDS = ("ue_x", "ue_y", "ue_hu", "g_x", "g_y", "g_fl", "g_v", "g_cos", "g_sin", "agg", "deagg", "tick",
-                "bs_xy", "serving", "fifo", "fifo_depth", "out_bits", "step_n", "ue_xy")
+STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
 class UavEnvStateLayout(C.Structure):
@@ -99,7 +98,7 @@ def load():
     lib.uavenv_set_state.argtypes = [_P, _P, C.c_int, _P]
     lib.uavenv_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.uavenv_philox4x32_10.restype = None
-    if lib.uavenv_abi_version() != 1:
+    if lib.uavenv_abi_version() != 2:
         raise UavEnvError("libuavenv.so ABI version mismatch")
     _lib = lib
     return lib

@@ -34,12 +34,14 @@ _OUT_SPECS = {
     "reward_f64": (torch.float64, lambda N, U, B: (N,)),
 }
 
-_STATE_DTYPES = {
-    "ue_x": np.float64, "ue_y": np.float64, "ue_hu": np.float64, "g_x": np.float64, "g_y": np.float64,
-    "g_fl": np.float64, "g_v": np.float64, "g_cos": np.float64, "g_sin": np.float64, "agg": np.int32,
-    "deagg": np.int32, "tick": np.uint32, "bs_xy": np.int32, "serving": np.int8, "fifo": np.int8,
-    "fifo_depth": np.int32, "out_bits": np.uint64, "step_n": np.int32, "ue_xy": np.int16,
+# Record formats of the state blob (include/uavenv.h, csrc/state_layout.h), little-endian, no implicit padding.
+_REC_DTYPES = {
+    "ue_pos": np.dtype([("x", "<f8"), ("y", "<f8")]),
+    "ue_aux": np.dtype([("hu", "<f8"), ("ix", "<i2"), ("iy", "<i2"), ("serving", "i1"), ("r0", "i1"), ("r1", "i1"), ("r2", "i1")]),
+    "grp": np.dtype([("x", "<f8"), ("y", "<f8"), ("fl", "<f8"), ("v", "<f8"), ("c", "<f8"), ("s", "<f8")]),
+    "env": np.dtype([("tick", "<u4"), ("agg", "<i4"), ("deagg", "<i4"), ("fifo_depth", "<i4"), ("step_n", "<i4"), ("pad", "<i4", (3,))]),
 }
+assert [_REC_DTYPES[k].itemsize for k in ("ue_pos", "ue_aux", "grp", "env")] == [16, 16, 48, 32]
 
 
 class BatchedMobiEnv:
@@ -270,20 +272,27 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_set_state(self._h, blob.ctypes.data, 0, self._stream()))
 
     def state_fields(self, blob=None):
-        """Named numpy views into a state blob (see UavEnvStateLayout in include/uavenv.h)."""
+        """The state blob decoded into named arrays (record formats: UavEnvStateLayout in include/uavenv.h).  Field views
+        alias the blob except ``fifo`` and ``ue_xy``, which are assembled from record members."""
         blob = self.get_state() if blob is None else blob
         N, U, B, Gr = self.n_envs, self.nUE, self.nBS, self.n_groups
         W64 = (U + 63) // 64
-        shapes = {"ue_x": (N, U), "ue_y": (N, U), "ue_hu": (N, U), "g_x": (N, Gr), "g_y": (N, Gr), "g_fl": (N, Gr),
-                  "g_v": (N, Gr), "g_cos": (N, Gr), "g_sin": (N, Gr), "agg": (N,), "deagg": (N,), "tick": (N,),
-                  "bs_xy": (N, B, 2), "serving": (N, U), "fifo": (N, 3, U), "fifo_depth": (N,),
-                  "out_bits": (N, W64), "step_n": (N,), "ue_xy": (N, U, 2)}
-        views = {}
-        for name, shp in shapes.items():
-            dt = np.dtype(_STATE_DTYPES[name])
-            off = getattr(self._lay, name)
-            n = int(np.prod(shp))
-            views[name] = blob[off:off + n * dt.itemsize].view(dt).reshape(shp)
+        def rec(name, shape):
+            dt, off = _REC_DTYPES[name], getattr(self._lay, name)
+            return blob[off:off + int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
+
+        def plain(name, dtype, shape):
+            dt, off = np.dtype(dtype), getattr(self._lay, name)
+            return blob[off:off + int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
+
+        pos, aux, grp, env = rec("ue_pos", (N, U)), rec("ue_aux", (N, U)), rec("grp", (N, Gr)), rec("env", (N,))
+        views = {"ue_x": pos["x"], "ue_y": pos["y"], "ue_hu": aux["hu"],
+                 "g_x": grp["x"], "g_y": grp["y"], "g_fl": grp["fl"], "g_v": grp["v"], "g_cos": grp["c"], "g_sin": grp["s"],
+                 "agg": env["agg"], "deagg": env["deagg"], "tick": env["tick"], "fifo_depth": env["fifo_depth"], "step_n": env["step_n"],
+                 "bs_xy": plain("bs_xy", np.int32, (N, B, 2)), "serving": aux["serving"],
+                 "fifo": np.stack([aux["r0"], aux["r1"], aux["r2"]], axis=1),          # [N, 3, U], oldest row first (a copy)
+                 "out_bits": plain("out_bits", np.uint64, (N, W64)),
+                 "ue_xy": np.stack([aux["ix"], aux["iy"]], axis=-1)}                   # [N, U, 2] (a copy)
         return views
 
     def clone(self):

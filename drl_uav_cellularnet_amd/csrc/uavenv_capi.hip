@@ -134,12 +134,17 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     if (!cfg || !out || n_envs < 1) return fail(UAVENV_E_INVALID, "create: null argument or n_envs < 1");
     if (int rc = check_config(*cfg)) return rc;
     {   // The kernels address state, outputs and actions as base + 32-bit byte offset (ldx/stx, uavenv_kernels.h): every array
-        // indexed that way must stay below 4 GiB.  Packed path (U <= 64, U >= B, U >= Gr): the widest row is U float64;
-        // multi-pass path: only the per-env scalars go through ldx/stx.  288 GB of HBM hold far larger batches: shard them
+        // indexed that way must stay below 4 GiB.  Packed path (U <= 64, U >= B, U >= Gr): walker records (16 B), group records
+        // (48 B), UAV cells (8 B); multi-pass path: only the per-env record (32 B) and per-env outputs go through ldx/stx.  288 GB of HBM hold far larger batches: shard them
         // over several handles (env_id_base keeps the Philox streams those of one big batch).
         const bool packed = (cfg->n_ue <= 64) && (cfg->n_ue >= cfg->n_bs) && (cfg->n_ue >= cfg->n_groups);
-        const unsigned long long row = packed ? (unsigned long long)cfg->n_ue : 1ull;
-        if ((unsigned long long)n_envs * row * 8ull > 0xFFFFFFFFull)
+        unsigned long long row = sizeof(EnvRec);                                    // bytes of the widest indexed array per env
+        if (packed) {
+            const unsigned long long cand[] = {(unsigned long long)cfg->n_ue * sizeof(UePos), (unsigned long long)cfg->n_groups * sizeof(GrpRec),
+                                               (unsigned long long)cfg->n_bs * 8ull};
+            for (unsigned long long c : cand) if (c > row) row = c;
+        }
+        if ((unsigned long long)n_envs * row > 0xFFFFFFFFull)
             return fail(UAVENV_E_INVALID, "create: n_envs too large for one handle (a state array would exceed 4 GiB); "
                                           "shard the batch over several handles with env_id_base");
     }
@@ -163,10 +168,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     const StateOffsets SO = compute_layout(n_envs, cfg->n_ue, cfg->n_bs, cfg->n_groups);
     UavEnvStateLayout &L = h->lay;
     L.total_bytes = SO.total;
-    L.ue_x = SO.ue_x; L.ue_y = SO.ue_y; L.ue_hu = SO.ue_hu;
-    L.g_x = SO.g_x; L.g_y = SO.g_y; L.g_fl = SO.g_fl; L.g_v = SO.g_v; L.g_cos = SO.g_cos; L.g_sin = SO.g_sin;
-    L.agg = SO.agg; L.deagg = SO.deagg; L.tick = SO.tick; L.bs_xy = SO.bs_xy; L.serving = SO.serving; L.fifo = SO.fifo;
-    L.fifo_depth = SO.fifo_depth; L.out_bits = SO.out_bits; L.step_n = SO.step_n; L.ue_xy = SO.ue_xy;
+    L.ue_pos = SO.ue_pos; L.ue_aux = SO.ue_aux; L.grp = SO.grp; L.env = SO.env; L.bs_xy = SO.bs_xy; L.out_bits = SO.out_bits;
 
     hipError_t e = hipMalloc((void **)&h->blob, L.total_bytes);
     if (e != hipSuccess) { delete h; return fail(UAVENV_E_NOMEM, std::string("create: hipMalloc state: ") + hipGetErrorString(e)); }
@@ -230,13 +232,8 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.grp_v_min = cfg->grp_v_min; k.grp_v_max = cfg->grp_v_max; k.aggregation = cfg->aggregation;
     k.N = n_envs; k.key0 = (uint32_t)seed; k.key1 = (uint32_t)(seed >> 32); k.env_id_base = env_id_base;
     char *b = h->blob;
-    k.ue_x = (double *)(b + L.ue_x); k.ue_y = (double *)(b + L.ue_y); k.ue_hu = (double *)(b + L.ue_hu);
-    k.g_x = (double *)(b + L.g_x); k.g_y = (double *)(b + L.g_y); k.g_fl = (double *)(b + L.g_fl);
-    k.g_v = (double *)(b + L.g_v); k.g_cos = (double *)(b + L.g_cos); k.g_sin = (double *)(b + L.g_sin);
-    k.agg = (int32_t *)(b + L.agg); k.deagg = (int32_t *)(b + L.deagg); k.tick = (uint32_t *)(b + L.tick);
-    k.bs_xy = (int32_t *)(b + L.bs_xy); k.serving = (int8_t *)(b + L.serving); k.fifo = (int8_t *)(b + L.fifo);
-    k.fifo_depth = (int32_t *)(b + L.fifo_depth); k.out_bits = (unsigned long long *)(b + L.out_bits);
-    k.step_n = (int32_t *)(b + L.step_n); k.ue_xy = (int16_t *)(b + L.ue_xy);
+    k.ue_pos = (UePos *)(b + L.ue_pos); k.ue_aux = (UeAux *)(b + L.ue_aux); k.grp = (GrpRec *)(b + L.grp);
+    k.env = (EnvRec *)(b + L.env); k.bs_xy = (int32_t *)(b + L.bs_xy); k.out_bits = (unsigned long long *)(b + L.out_bits);
     k.bs_init = h->bs_init_dev;
     k.act_pow = h->act_pow_dev;
     k.gid_of_u = h->gid_dev;
@@ -275,10 +272,8 @@ extern "C" int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *strea
     p.U = k.U; p.Gr = k.Gr; p.B = k.B; p.W64 = k.W64; p.G = k.G; p.agg_init = k.agg_init; p.deagg_len = k.deagg_len;
     p.grp_v_min = k.grp_v_min; p.grp_v_max = k.grp_v_max; p.N = k.N; p.key0 = k.key0; p.key1 = k.key1;
     p.env_id_base = k.env_id_base;
-    p.ue_x = k.ue_x; p.ue_y = k.ue_y; p.ue_hu = k.ue_hu; p.g_x = k.g_x; p.g_y = k.g_y; p.g_fl = k.g_fl; p.g_v = k.g_v;
-    p.g_cos = k.g_cos; p.g_sin = k.g_sin; p.agg = k.agg; p.deagg = k.deagg; p.tick = k.tick; p.bs_xy = k.bs_xy;
-    p.serving = k.serving; p.fifo = k.fifo; p.fifo_depth = k.fifo_depth; p.out_bits = k.out_bits; p.step_n = k.step_n;
-    p.ue_xy = k.ue_xy; p.bs_init = k.bs_init;
+    p.ue_pos = k.ue_pos; p.ue_aux = k.ue_aux; p.grp = k.grp; p.env = k.env; p.bs_xy = k.bs_xy; p.out_bits = k.out_bits;
+    p.bs_init = k.bs_init;
     if (inj) { p.u_x = inj->u_x_dev; p.u_y = inj->u_y_dev; p.u_th = inj->u_th_dev; p.u_g = inj->u_g_dev; }
     p.per = k.U;
     if (k.Gr > p.per) p.per = k.Gr;
@@ -438,7 +433,7 @@ extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     HIP_TRY(hipMemsetAsync(obs_dev, 0, bytes, (hipStream_t)stream));
     const long long total = k.N * (k.U + k.B);
     hipLaunchKernelGGL((obs_cells_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, h->obs_prev_dev, obs_dev);
+                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_aux, h->obs_prev_dev, obs_dev);
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }
@@ -450,7 +445,7 @@ extern "C" int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream
     const KParams &k = h->kp;
     const long long total = k.N * (k.U + k.B);
     hipLaunchKernelGGL((obs_cells_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_xy, k.serving, h->obs_prev_dev, obs_dev);
+                       k.N, k.U, k.B, k.G, k.bs_xy, k.ue_aux, h->obs_prev_dev, obs_dev);
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }

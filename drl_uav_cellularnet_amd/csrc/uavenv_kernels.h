@@ -88,10 +88,8 @@ struct KParams {
     double shadow_mean, shadow_sd, ho_thresh_db, out_thresh, ue_velocity, grp_v_min, grp_v_max, aggregation;
     long long N;
     uint32_t key0, key1, env_id_base;
-    // persistent state (SoA, [field][env][...])
-    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
-    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
-    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
+    // persistent state: arrays of records, [field][env][...] (state_layout.h)
+    UePos *ue_pos; UeAux *ue_aux; GrpRec *grp; EnvRec *env; int32_t *bs_xy; unsigned long long *out_bits;   // state_layout.h
     const int32_t *bs_init;      // [B,2] device copy of the start cells
     const long long *act_pow;    // [B]   n_act^(B-1-b): joint action -> digit of UAV b (most significant first)
     const int8_t *gid_of_u;      // [U]   RPGM group of walker u (from group_size)
@@ -106,18 +104,15 @@ struct InitParams {
     int U, Gr, B, W64, G, per; int agg_init, deagg_len;
     double grp_v_min, grp_v_max;
     long long N; uint32_t key0, key1, env_id_base;
-    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
-    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
-    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy; const int32_t *bs_init;
+    UePos *ue_pos; UeAux *ue_aux; GrpRec *grp; EnvRec *env; int32_t *bs_xy; unsigned long long *out_bits;   // state_layout.h
+    const int32_t *bs_init;
     const double *u_x, *u_y, *u_th, *u_g;
 };
 
 // Typed pointers to the state fields of one handle.  The packed kernel builds them from the slab base + the shared
 // layout function (scalar arithmetic on preloaded arguments); the multi-pass kernel copies them from KParams.
 struct StatePtrs {
-    double *ue_x, *ue_y, *ue_hu, *g_x, *g_y, *g_fl, *g_v, *g_cos, *g_sin;
-    int32_t *agg, *deagg; uint32_t *tick; int32_t *bs_xy; int8_t *serving; int8_t *fifo; int32_t *fifo_depth;
-    unsigned long long *out_bits; int32_t *step_n; int16_t *ue_xy;
+    UePos *ue_pos; UeAux *ue_aux; GrpRec *grp; EnvRec *env; int32_t *bs_xy; unsigned long long *out_bits;   // state_layout.h
 };
 // Element access as  uniform base + 32-bit byte offset.  hipcc then emits the SGPR-base form
 // (global_load_dwordx2 v[..], v_off, s[base:base+1]) instead of one 64-bit VGPR address per array: arrays indexed alike share
@@ -147,22 +142,14 @@ template <bool LOCAL> __device__ __forceinline__ uint32_t block_local(uint32_t i
 __device__ __forceinline__ StatePtrs state_from_blob(char *b, long long N, int U, int B, int Gr) {
     const StateOffsets L = compute_layout(N, U, B, Gr);
     StatePtrs s;
-    s.ue_x = (double *)(b + L.ue_x); s.ue_y = (double *)(b + L.ue_y); s.ue_hu = (double *)(b + L.ue_hu);
-    s.g_x = (double *)(b + L.g_x); s.g_y = (double *)(b + L.g_y); s.g_fl = (double *)(b + L.g_fl);
-    s.g_v = (double *)(b + L.g_v); s.g_cos = (double *)(b + L.g_cos); s.g_sin = (double *)(b + L.g_sin);
-    s.agg = (int32_t *)(b + L.agg); s.deagg = (int32_t *)(b + L.deagg); s.tick = (uint32_t *)(b + L.tick);
-    s.bs_xy = (int32_t *)(b + L.bs_xy); s.serving = (int8_t *)(b + L.serving); s.fifo = (int8_t *)(b + L.fifo);
-    s.fifo_depth = (int32_t *)(b + L.fifo_depth); s.out_bits = (unsigned long long *)(b + L.out_bits);
-    s.step_n = (int32_t *)(b + L.step_n); s.ue_xy = (int16_t *)(b + L.ue_xy);
+    s.ue_pos = (UePos *)(b + L.ue_pos); s.ue_aux = (UeAux *)(b + L.ue_aux); s.grp = (GrpRec *)(b + L.grp);
+    s.env = (EnvRec *)(b + L.env); s.bs_xy = (int32_t *)(b + L.bs_xy); s.out_bits = (unsigned long long *)(b + L.out_bits);
     return s;
 }
 
 __device__ __forceinline__ StatePtrs state_from_params(const KParams &p) {
     StatePtrs s;
-    s.ue_x = p.ue_x; s.ue_y = p.ue_y; s.ue_hu = p.ue_hu; s.g_x = p.g_x; s.g_y = p.g_y; s.g_fl = p.g_fl; s.g_v = p.g_v;
-    s.g_cos = p.g_cos; s.g_sin = p.g_sin; s.agg = p.agg; s.deagg = p.deagg; s.tick = p.tick; s.bs_xy = p.bs_xy;
-    s.serving = p.serving; s.fifo = p.fifo; s.fifo_depth = p.fifo_depth; s.out_bits = p.out_bits; s.step_n = p.step_n;
-    s.ue_xy = p.ue_xy;
+    s.ue_pos = p.ue_pos; s.ue_aux = p.ue_aux; s.grp = p.grp; s.env = p.env; s.bs_xy = p.bs_xy; s.out_bits = p.out_bits;
     return s;
 }
 
@@ -514,14 +501,16 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 }
 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
+// `rec` is the env's record as loaded at kernel entry: fields a mode does not own keep their value (the aggregation counters in
+// the trace modes, depth and step count during warm-up), and the whole record goes back with one 32-byte store.
 template <int MODE, bool FAST>
-__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, uint32_t e, uint32_t tick, int agg, int deagg, int depth,
-                                           int step_n, double sum_cur, int n_outage) {
-    stx(st.tick, e, tick);
-    if (has_mobility(MODE)) { stx(st.agg, e, agg); stx(st.deagg, e, deagg); }
+__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, uint32_t e, EnvRec rec, uint32_t tick, int agg, int deagg,
+                                           int depth, int step_n, double sum_cur, int n_outage) {
+    rec.tick = tick;
+    if (has_mobility(MODE)) { rec.agg = agg; rec.deagg = deagg; }
     if (is_reset(MODE)) {
-        stx(st.fifo_depth, e, 1);                              // bestBS_buf = [current_BS] (channel.py:115)
-        stx(st.step_n, e, 0);                                  // mobile_env.py:146
+        rec.fifo_depth = 1;                                    // bestBS_buf = [current_BS] (channel.py:115)
+        rec.step_n = 0;                                        // mobile_env.py:146
         const double mean = sum_cur * p.inv_U;
         if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, 0);
         if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, 0.f);
@@ -532,14 +521,14 @@ __device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st
         if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
     }
     if (is_step(MODE)) {
-        if (depth < 3) stx(st.fifo_depth, e, depth + 1);
+        rec.fifo_depth = depth < 3 ? depth + 1 : depth;
         const double mean = sum_cur * p.inv_U;                // channel.py:216 (np.mean; <= 1 ulp from sum/U)
         const double r0 = sum_cur * p.inv_U20;                // mobile_env.py:165  mean / 20
         const double r1 = -((double)n_outage * p.inv_U);      // mobile_env.py:167  -1.0 * nOut / nUE
         double reward = (0.0 + r0) + r1;                      // sum(r_dissect)
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
-        stx(st.step_n, e, step_n);
+        rec.step_n = step_n;
         if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, step_n);
         if (UAV_OUT(p.out.done)) stx(p.out.done, e, (uint8_t)(step_n >= p.max_step));
         if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, (float)reward);
@@ -548,6 +537,7 @@ __device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st
         if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
         if (UAV_OUT(p.out.n_out)) stx(p.out.n_out, e, n_outage);
     }
+    stx(st.env, e, rec);
 }
 
 // ================================================================================================
@@ -571,12 +561,8 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
             r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)u, DOM_INIT_UE_B, p.key0, p.key1);
             ut = u53(r.x, r.y);
         }
-        p.ue_x[t] = ux * MAXC;  // :434
-        p.ue_y[t] = uy * MAXC;  // :435
-        p.ue_hu[t] = ut;        // :437 (cos/sin are taken when the heading is used, :455)
-        p.serving[t] = 0;
-        p.fifo[(e * 3 + 0) * U + u] = 0; p.fifo[(e * 3 + 1) * U + u] = 0; p.fifo[(e * 3 + 2) * U + u] = 0;
-        p.ue_xy[2 * t] = 0; p.ue_xy[2 * t + 1] = 0;
+        p.ue_pos[t] = UePos{ux * MAXC, uy * MAXC};         // :434-435
+        p.ue_aux[t] = UeAux{ut, 0, 0, 0, 0, 0, 0};         // :437 (cos/sin are taken when the heading is used, :455)
     }
     if (u < Gr) {
         const int g = u;
@@ -590,22 +576,16 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
             r = philox4x32_10(p.env_id_base + (uint32_t)e, 0xFFFFFFFFu, (uint32_t)g, DOM_INIT_G_C, p.key0, p.key1);
             v[4] = u53(r.x, r.y);
         }
-        p.g_x[e * Gr + g] = v[0] * MAXC;   // :442
-        p.g_y[e * Gr + g] = v[1] * MAXC;   // :443 (MAX_X, sic)
-        p.g_fl[e * Gr + g] = v[2] * MAXC;  // :444
-        p.g_v[e * Gr + g] = v[3] * (p.grp_v_max - p.grp_v_min) + p.grp_v_min;  // :445
         const double th = v[4] * two_pi;   // :446
-        p.g_cos[e * Gr + g] = cos(th);
-        p.g_sin[e * Gr + g] = sin(th);
+        // :442 x, :443 y (MAX_X, sic), :444 flight length, :445 speed
+        p.grp[e * Gr + g] = GrpRec{v[0] * MAXC, v[1] * MAXC, v[2] * MAXC, v[3] * (p.grp_v_max - p.grp_v_min) + p.grp_v_min, cos(th), sin(th)};
     }
     if (u < p.B) {
         p.bs_xy[(e * p.B + u) * 2] = p.bs_init[2 * u];
         p.bs_xy[(e * p.B + u) * 2 + 1] = p.bs_init[2 * u + 1];
     }
     if (u < p.W64) p.out_bits[e * p.W64 + u] = 0ull;
-    if (u == 0) {
-        p.agg[e] = p.agg_init; p.deagg[e] = p.deagg_len; p.tick[e] = 0u; p.fifo_depth[e] = 0; p.step_n[e] = 0;
-    }
+    if (u == 0) p.env[e] = EnvRec{0u, p.agg_init, p.deagg_len, 0, 0, 0, 0, 0};
 }
 
 // ================================================================================================
@@ -641,10 +621,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
     const long long iu = e * U + (live ? u : 0);
-    // 32-bit element indices for ldx()/stx(): env, walker [N,U], group [N,Gr], UAV [N,B], FIFO row 0 [N,3,U]
+    // 32-bit element indices for ldx()/stx(): env, walker [N,U], group [N,Gr], UAV [N,B]
     const uint32_t e32 = (uint32_t)e, iu32 = (uint32_t)iu;
     const uint32_t ig32 = e32 * (uint32_t)Gr + (uint32_t)ul, ib32 = e32 * (uint32_t)B + (uint32_t)ul;
-    const uint32_t if32 = e32 * 3u * (uint32_t)U + (uint32_t)u;
     const bool head = live && (ul == 0);                             // writes the per-env scalars
     const bool bown = (MODE != MODE_WARMUP) && live && (ul < B);     // this lane owns UAV `ul`
     const bool gown = (has_mobility(MODE)) && live && (ul < Gr);     // this lane owns RPGM group `ul`
@@ -671,36 +650,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             if (is_step(MODE)) { act = ldx(actions, e32); apw = p.act_pow[ul]; }
         }
     }
-    uint32_t tick = ldx(st.tick, e32);
-    int agg = 0, deagg = 0;
-    if (has_mobility(MODE)) { agg = ldx(st.agg, e32); deagg = ldx(st.deagg, e32); }
-    int depth = 0, step_n = 0;
-    if (is_step(MODE)) { depth = ldx(st.fifo_depth, e32); step_n = ldx(st.step_n, e32); }
+    const EnvRec erec = ldx(st.env, e32);                      // tick, phase counters, FIFO depth, step count: one record
+    uint32_t tick = erec.tick;
+    int agg = erec.agg, deagg = erec.deagg;
+    const int depth = erec.fifo_depth;
+    const int step_n = erec.step_n;
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
-        ogx = ldx(st.g_x, ig32); ogy = ldx(st.g_y, ig32); ogfl = ldx(st.g_fl, ig32);
-        ogv = ldx(st.g_v, ig32); ogc = ldx(st.g_cos, ig32); ogs = ldx(st.g_sin, ig32);
+        const GrpRec g = ldx(st.grp, ig32);
+        ogx = g.x; ogy = g.y; ogfl = g.fl; ogv = g.v; ogc = g.c; ogs = g.s;
     }
     double x = 0, y = 0, hu = 0, hu_inj = 0;
     int ix = 0, iy = 0, gid = 0;
+    int serving = 0, r0 = 0, r1 = 0, r2 = 0;
+    if (live) {                                                   // heading, integer cell, serving UAV and FIFO rows: one record
+        const UeAux a = ldx(st.ue_aux, iu32);
+        hu = a.hu; ix = a.ix; iy = a.iy; serving = a.serving; r0 = a.r0; r1 = a.r1; r2 = a.r2;
+    }
     if (has_mobility(MODE)) {
         gid = ldx(gid_of_u, (uint32_t)u);                          // table padded to >= 64 entries: dead lanes have u < 64
         if (live) {
-            x = ldx(st.ue_x, iu32); y = ldx(st.ue_y, iu32); hu = ldx(st.ue_hu, iu32);
+            const UePos q = ldx(st.ue_pos, iu32);
+            x = q.x; y = q.y;
             if (UAV_INJ(p.inj_theta)) hu_inj = p.inj_theta[iu];   // injected draws cover exactly one tick
         }
     } else if (live) {                                            // mobile_env.py:202-203 (read_trace)
         ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
     }
-    int serving = 0, r0 = 0, r1 = 0, r2 = 0;
     unsigned long long prev_out = 0ull;
-    if (is_step(MODE)) {
-        if (live) {
-            serving = ldx(st.serving, iu32);
-            r0 = ldx(st.fifo, if32); r1 = ldx(st.fifo, if32 + (uint32_t)U); r2 = ldx(st.fifo, if32 + 2u * (uint32_t)U);
-        }
-        prev_out = ldx(st.out_bits, e32);                          // one 64-bit word per env here (U <= 64)
-    }
+    if (is_step(MODE)) prev_out = ldx(st.out_bits, e32);           // one 64-bit word per env here (U <= 64)
 
     // Only now touch the parameter struct: its (cold) kernarg fetch overlaps the global loads issued above.
     __builtin_amdgcn_sched_barrier(0);
@@ -818,13 +796,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
 
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
-        const uint32_t iw = block_local<!PIN>(iu32), fw = block_local<!PIN>(if32);
-        if (has_mobility(MODE)) { stx(st.ue_x, iw, x); stx(st.ue_y, iw, y); stx(st.ue_hu, iw, hu); }
-        stx(st.ue_xy, 2u * iw, (int16_t)ix); stx(st.ue_xy, 2u * iw + 1u, (int16_t)iy);
+        const uint32_t iw = block_local<!PIN>(iu32);
+        if (has_mobility(MODE)) stx(st.ue_pos, iw, UePos{x, y});
+        // warm-up leaves serving and the FIFO rows as loaded; a reset overwrites serving and row 0 only (depth becomes 1)
+        stx(st.ue_aux, iw, UeAux{hu, (int16_t)ix, (int16_t)iy, (int8_t)serving, (int8_t)r0, (int8_t)r1, (int8_t)r2});
         if (MODE != MODE_WARMUP) {
-            stx(st.serving, iw, (int8_t)serving);
-            stx(st.fifo, fw, (int8_t)r0);
-            if (!is_reset(MODE)) { stx(st.fifo, fw + (uint32_t)U, (int8_t)r1); stx(st.fifo, fw + 2u * (uint32_t)U, (int8_t)r2); }
             if (UAV_OUT(p.out.ue_xy)) { stx(p.out.ue_xy, 2u * iw, (int16_t)ix); stx(p.out.ue_xy, 2u * iw + 1u, (int16_t)iy); }
             if (UAV_OUT(p.out.serving)) stx(p.out.serving, iw, (int8_t)serving);
             if (UAV_OUT(p.out.cur_sinr)) stx(p.out.cur_sinr, iw, (float)cur);
@@ -833,8 +809,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     }
     if (gown) {
         const uint32_t gw = block_local<!PIN>(ig32);
-        stx(st.g_x, gw, ogx); stx(st.g_y, gw, ogy); stx(st.g_fl, gw, ogfl);
-        stx(st.g_v, gw, ogv); stx(st.g_cos, gw, ogc); stx(st.g_sin, gw, ogs);
+        stx(st.grp, gw, GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs});
     }
     if (bown) {
         const uint32_t bw = block_local<!PIN>(ib32);
@@ -844,7 +819,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     if (head) {
         const uint32_t ew = block_local<!PIN>(e32);
         if (MODE != MODE_WARMUP) stx(st.out_bits, ew, ob);                                // :116 / :173
-        env_finish<MODE, FAST>(p, st, ew, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        env_finish<MODE, FAST>(p, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -914,11 +889,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         if (MODE != MODE_WARMUP && b < B) { bsx[b] = s_bs[wave][2 * b]; bsy[b] = s_bs[wave][2 * b + 1]; }
     }
 
-    int agg = 0, deagg = 0;
-    uint32_t tick = st.tick[e];
-    if (has_mobility(MODE)) { agg = st.agg[e]; deagg = st.deagg[e]; }
-    int depth = 0, step_n = 0;
-    if (is_step(MODE)) { depth = st.fifo_depth[e]; step_n = st.step_n[e]; }
+    const EnvRec erec = st.env[e];
+    int agg = erec.agg, deagg = erec.deagg;
+    uint32_t tick = erec.tick;
+    const int depth = erec.fifo_depth, step_n = erec.step_n;
     const bool gown = lane < Gr;
 
     double sum_cur = 0.0;
@@ -929,8 +903,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         const bool aggregating = agg != 0;
         if (has_mobility(MODE)) {
             if (gown) {
-                ogx = st.g_x[e * Gr + lane]; ogy = st.g_y[e * Gr + lane]; ogfl = st.g_fl[e * Gr + lane];
-                ogv = st.g_v[e * Gr + lane]; ogc = st.g_cos[e * Gr + lane]; ogs = st.g_sin[e * Gr + lane];
+                const GrpRec g = st.grp[e * Gr + lane];
+                ogx = g.x; ogy = g.y; ogfl = g.fl; ogv = g.v; ogc = g.c; ogs = g.s;
                 ogx = ogx + ogv * ogc;
                 ogy = ogy + ogv * ogs;
             }
@@ -942,13 +916,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             const bool act = u < U;
             const long long iu = e * U + (act ? u : 0);
             int ix = 0, iy = 0;
+            UeAux aux = st.ue_aux[iu];                            // inactive lanes read walker 0 of the env and store nothing
             if (has_mobility(MODE)) {
                 int gid = 0;
                 for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
                 const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
-                double x = 0, y = 0, hu = 0;
-                if (act) { x = st.ue_x[iu]; y = st.ue_y[iu]; hu = st.ue_hu[iu]; }
+                double x = 0, y = 0, hu = aux.hu;
+                if (act) { const UePos q = st.ue_pos[iu]; x = q.x; y = q.y; }
                 bool c[4];
                 walker_move(H, C, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
                 c[0] = c[0] && act; c[1] = c[1] && act; c[2] = c[2] && act; c[3] = c[3] && act;
@@ -968,15 +943,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                     hu = heading_from(h0, h1, HB);
                 }
                 ix = (int)x; iy = (int)y;
-                if (act) {
-                    st.ue_x[iu] = x; st.ue_y[iu] = y; st.ue_hu[iu] = hu;
-                    st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
-                }
+                aux.hu = hu;
+                if (act) st.ue_pos[iu] = UePos{x, y};
             } else if (act) {
                 ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
-                st.ue_xy[2 * iu] = (int16_t)ix; st.ue_xy[2 * iu + 1] = (int16_t)iy;
             }
-            if (MODE == MODE_WARMUP) continue;
+            aux.ix = (int16_t)ix; aux.iy = (int16_t)iy;
+            if (MODE == MODE_WARMUP) { if (act) st.ue_aux[iu] = aux; continue; }
             if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
 
             double pg[BT];
@@ -987,19 +960,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                 const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
                 if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
-                    st.serving[iu] = (int8_t)best;
-                    st.fifo[(e * 3 + 0) * U + u] = (int8_t)best;
+                    aux.serving = (int8_t)best; aux.r0 = (int8_t)best;
+                    st.ue_aux[iu] = aux;
                     if (p.out.serving) p.out.serving[iu] = (int8_t)best;
                     if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
                     if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
                 }
                 sum_cur += wave_sum(act ? bestS : 0.0);
             } else {
-                int serving = 0, r0 = 0, r1 = 0, r2 = 0;
-                if (act) {
-                    serving = st.serving[iu];
-                    r0 = st.fifo[(e * 3 + 0) * U + u]; r1 = st.fifo[(e * 3 + 1) * U + u]; r2 = st.fifo[(e * 3 + 2) * U + u];
-                }
+                int serving = aux.serving, r0 = aux.r0, r1 = aux.r1, r2 = aux.r2;
                 const double cur = sinr_db<BT, FAST>(p, H, C, pg, serving);
                 fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
                 const unsigned long long ob = __ballot(act && (cur <= H.out_thr));
@@ -1007,10 +976,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                 n_outage += __popcll(ob & ~prev);
                 if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
                 if (act) {
-                    st.serving[iu] = (int8_t)serving;
-                    st.fifo[(e * 3 + 0) * U + u] = (int8_t)r0;
-                    st.fifo[(e * 3 + 1) * U + u] = (int8_t)r1;
-                    st.fifo[(e * 3 + 2) * U + u] = (int8_t)r2;
+                    aux.serving = (int8_t)serving; aux.r0 = (int8_t)r0; aux.r1 = (int8_t)r1; aux.r2 = (int8_t)r2;
+                    st.ue_aux[iu] = aux;
                     if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
                     if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
                     if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
@@ -1022,15 +989,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         if (has_mobility(MODE)) {
             if (gown) {
                 group_finish<FAST>(p, C, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
-                st.g_x[e * Gr + lane] = ogx; st.g_y[e * Gr + lane] = ogy; st.g_fl[e * Gr + lane] = ogfl;
-                st.g_v[e * Gr + lane] = ogv; st.g_cos[e * Gr + lane] = ogc; st.g_sin[e * Gr + lane] = ogs;
+                st.grp[e * Gr + lane] = GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs};
             }
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }
         }
         tick += 1u;
     }
-    if (lane == 0) env_finish<MODE, FAST>(p, st, (uint32_t)e, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (lane == 0) env_finish<MODE, FAST>(p, st, (uint32_t)e, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
 // ================================================================================================
@@ -1038,11 +1004,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 // ================================================================================================
 // Flat index (inside one env's (B+1, G, G) block) of node k: k < B the UAV cells of plane 0, else UE k-B in the plane
 // of its serving UAV; -1 when the cell is outside the grid (the reference would raise IndexError).
-__device__ __forceinline__ int obs_cell(long long e, int k, int U, int B, int G, const int32_t *bs_xy, const int16_t *ue_xy,
-                                        const int8_t *serving) {
+__device__ __forceinline__ int obs_cell(long long e, int k, int U, int B, int G, const int32_t *bs_xy, const UeAux *ue_aux) {
     int x, y, pl;
     if (k < B) { x = bs_xy[(e * B + k) * 2]; y = bs_xy[(e * B + k) * 2 + 1]; pl = 0; }
-    else { const int u = k - B; x = ue_xy[(e * U + u) * 2]; y = ue_xy[(e * U + u) * 2 + 1]; pl = 1 + serving[e * U + u]; }
+    else { const UeAux a = ue_aux[e * U + (k - B)]; x = a.ix; y = a.iy; pl = 1 + a.serving; }
     if (x < 0 || x >= G || y < 0 || y >= G) return -1;
     return (pl * G + x) * G + y;
 }
@@ -1051,14 +1016,14 @@ __device__ __forceinline__ int obs_cell(long long e, int k, int U, int B, int G,
 // the cells that changed.  Counts are small integers in float32, so +-1.0f is exact and the order of atomics is irrelevant.
 template <bool UPDATE>
 __global__ __launch_bounds__(256) void obs_cells_kernel(long long N, int U, int B, int G, const int32_t *bs_xy,
-                                                        const int16_t *ue_xy, const int8_t *serving, int32_t *prev, float *obs) {
+                                                        const UeAux *ue_aux, int32_t *prev, float *obs) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = U + B;
     if (t >= N * per) return;
     const long long e = t / per;
     const int k = (int)(t - e * per);
     const long long base = e * (long long)(B + 1) * G * G;
-    const int now = obs_cell(e, k, U, B, G, bs_xy, ue_xy, serving);
+    const int now = obs_cell(e, k, U, B, G, bs_xy, ue_aux);
     if (UPDATE) {
         const int old = prev[t];
         if (old == now) return;
@@ -1115,7 +1080,7 @@ __global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const d
                 if (b1 < B) f1 = fading_inj[base + (b1 == near ? B - 1 : (b1 < near ? b1 : b1 - 1))];
             } else {
                 double u0, u1;
-                philox_u2(p, (uint32_t)e, p.tick[e], (uint32_t)(c * ((B + 1) >> 1) + (b2 >> 1)), DOM_AREA, u0, u1);
+                philox_u2(p, (uint32_t)e, p.env[e].tick, (uint32_t)(c * ((B + 1) >> 1) + (b2 >> 1)), DOM_AREA, u0, u1);
                 const double tt = -2.0 * lm_logc(1.0 - u0, C);
                 const double r = (tt > 0.0) ? tt * lm_rsqrt(tt) : 0.0;
                 double sa, ca;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 1
+#define UAVENV_ABI_VERSION 2   /* 2: state blob = arrays of records (UavEnvStateLayout); entry points unchanged */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -84,20 +84,17 @@ typedef struct UavEnvOut {
     double *cur_sinr_f64_dev, *mean_sinr_f64_dev, *reward_f64_dev; /* optional float64 copies       */
 } UavEnvOut;
 
-/* Byte offsets of every persistent per-env field inside the state blob (get/set_state). */
+/* Byte offsets of the persistent state arrays inside the state blob (get/set_state).  Arrays of little-endian records (ABI 2;
+ * ABI 1 had one array per scalar field -- same bytes, but the step kernel is bound by memory-instruction issue):
+ *   ue_pos  [N,U]  16 B  { f64 x, y }                                          walker position in cells
+ *   ue_aux  [N,U]  16 B  { f64 heading_uniform; i16 ix, iy; i8 serving, fifo0, fifo1, fifo2 }   fifo0 = oldest bestBS_buf row
+ *   grp     [N,Gr] 48 B  { f64 x, y, flight_len, speed, cos, sin }             RPGM group
+ *   env     [N]    32 B  { u32 tick; i32 agg, deagg, fifo_depth, step_n; i32 pad[3] }
+ *   bs_xy   [N,B,2] i32;   out_bits [N,ceil(U/64)] u64  previous outage set
+ * drl_uav_cellularnet_amd.BatchedMobiEnv.state_fields() decodes a blob into named arrays. */
 typedef struct UavEnvStateLayout {
     size_t total_bytes;
-    size_t ue_x, ue_y, ue_hu;                     /* f64 [N,U]                                        */
-    size_t g_x, g_y, g_fl, g_v, g_cos, g_sin;     /* f64 [N,Gr]                                       */
-    size_t agg, deagg;                            /* i32 [N]                                          */
-    size_t tick;                                  /* u32 [N]                                          */
-    size_t bs_xy;                                 /* i32 [N,B,2]                                      */
-    size_t serving;                               /* i8  [N,U]                                        */
-    size_t fifo;                                  /* i8  [N,3,U]   bestBS_buf, oldest row first       */
-    size_t fifo_depth;                            /* i32 [N]                                          */
-    size_t out_bits;                              /* u64 [N,ceil(U/64)]  previous outage set          */
-    size_t step_n;                                /* i32 [N]                                          */
-    size_t ue_xy;                                 /* i16 [N,U,2]                                      */
+    size_t ue_pos, ue_aux, grp, env, bs_xy, out_bits;
 } UavEnvStateLayout;
 
 typedef struct uavenv uavenv_t;
@@ -110,8 +107,8 @@ int uavenv_default_config(UavEnvConfig *cfg, int n_bs, int n_ue, int grid);
 
 /* Allocate N envs on `device`.  env_id_base offsets the Philox env id (rank * N for sharding).
  * UAVENV_E_INVALID (see uavenv_last_error) for a config check_config rejects, and for a batch too large for ONE handle: the
- * kernels address each state / output array as base + 32-bit byte offset, so n_envs * n_ue * 8 must stay below 4 GiB when
- * n_ue <= 64 (26.8 M envs at n_ue = 20), and n_envs * 8 otherwise.  Larger batches: several handles with consecutive
+ * kernels address each state / output array as base + 32-bit byte offset, so n_envs * max(16 n_ue, 48 n_groups) must stay below
+ * 4 GiB when n_ue <= 64 (13.4 M envs at n_ue = 20), and n_envs * 32 otherwise.  Larger batches: several handles with consecutive
  * env_id_base ranges, which are bit-identical to one big batch. */
 int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device, uint64_t seed, uint32_t env_id_base,
                   uavenv_t **out);

@@ -52,7 +52,7 @@ def test_host_side_calls_without_gpu():
     from drl_uav_cellularnet_amd import _capi
 
     lib = _capi.load()
-    assert lib.uavenv_abi_version() == 1
+    assert lib.uavenv_abi_version() == 2
     cfg = _capi.make_config(4, 40, 100)
     assert [cfg.bs_init_xy[b][0] for b in range(4)] == [25, 25, 75, 75]  # mobile_env.py:49
     assert [cfg.bs_init_xy[b][1] for b in range(4)] == [25, 75, 25, 75]  # mobile_env.py:50
@@ -73,14 +73,14 @@ def test_create_validates_before_touching_the_device():
     lib = _capi.load()
     h = ctypes.c_void_p()
     cfg = _capi.make_config(4, 20, 100)
-    limit = 0xFFFFFFFF // (20 * 8)                      # packed path: widest row = 20 float64
+    limit = 0xFFFFFFFF // (20 * 16)                     # packed path: widest array per env = 20 walker records of 16 bytes
     assert lib.uavenv_create(ctypes.byref(cfg), limit + 1, 0, 1, 0, ctypes.byref(h)) == -1
     assert b"too large" in lib.uavenv_last_error() and not h.value
     if not torch.cuda.is_available():                    # exactly at the limit the size check passes; here the next check fails
         assert lib.uavenv_create(ctypes.byref(cfg), limit, 0, 1, 0, ctypes.byref(h)) != 0
         assert b"too large" not in lib.uavenv_last_error() and b"HIP device" in lib.uavenv_last_error()
-    big = _capi.make_config(16, 200, 100, bs_init=[(5 + 6 * b, 50) for b in range(16)])   # multi-pass: only N * 8 is bounded
-    assert lib.uavenv_create(ctypes.byref(big), 0xFFFFFFFF // 8 + 1, 0, 1, 0, ctypes.byref(h)) == -1
+    big = _capi.make_config(16, 200, 100, bs_init=[(5 + 6 * b, 50) for b in range(16)])   # multi-pass: only per-env arrays
+    assert lib.uavenv_create(ctypes.byref(big), 0xFFFFFFFF // 32 + 1, 0, 1, 0, ctypes.byref(h)) == -1   # the 32-byte env record
     assert b"too large" in lib.uavenv_last_error()
     for cell in ((0, 50), (50, 0), (100, 50), (50, 100), (-1, 50)):
         bad = _capi.make_config(4, 20, 100)
