@@ -143,6 +143,13 @@ PHILOX_SHAPES = [
                                                # MOVED coordinate is range-checked (:221-253), so they may slide along a wall
     (7, 33, 64, 8, 40, {"n_act": 9}),          # checked variant (B = 7 < BT = 8)
     (16, 200, 100, 4, 12, {"n_act": 9}),       # multi-pass, 9^16 needs the 64-bit digit path
+    # the extremes check_config() allows
+    (2, 4096, 100, 2, 3, {}),                  # n_ue at its maximum: 64 passes, 64-word outage mask per env
+    (4, 1000, 100, 3, 4, {}),                  # 16 passes, last one with 40 of 64 lanes
+    (1, 1, 16, 5, 30, {}),                     # ONE walker: groups [0, 0, 0, 1] (three empty groups), multi-pass because U < Gr
+    (4, 20, 8, 7, 40, {}),                     # the smallest grid (8 x 8): UAVs 4 cells apart, frozen by the distance rule
+    (4, 4, 32, 40, 40, {}),                    # U == B == Gr: every lane of a slot is walker, group owner and UAV owner; 8 envs per wave (kMaxEpw caps 16)
+    (8, 64, 100, 3, 12, {}),                   # packed, BT = 8 with B = 8 (FAST), full-wavefront slots
 ]
 
 
