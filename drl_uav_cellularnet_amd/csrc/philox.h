@@ -2,6 +2,7 @@
 // Replaces the reference's process-global MT19937 draws (ue_mobility.py:6,408,508; channel.py:240):
 // one independent stream per (env, tick, index, draw site), so results do not depend on scheduling.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -32,9 +33,16 @@ UAVENV_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     return U4{c0, c1, c2, c3};
 }
 
-// 53-bit uniform in [0,1) from two words
-UAVENV_HD double u53(uint32_t hi, uint32_t lo) {
+// 53-bit uniform in [0,1) from two words: ((hi >> 5) * 2^26 + (lo >> 6)) * 2^-53, the construction NumPy's random_sample uses.
+// Evaluated as a * 2^-27 + b * 2^-53 with a = hi >> 5 < 2^27 and b = lo >> 6 < 2^26: both u32 -> f64 converts are exact, both
+// scalings are by powers of two, and the sum is a 53-bit integer times 2^-53, hence representable -- the fma returns exactly the
+// value of the integer formulation (u53_int below; gfx950 has no u64 -> f64 convert, that form costs ~10 instructions, this one 6).
+// Equality is checked for edge and random words in tests/native/lean_math_check.cpp; the oracle keeps the integer form.
+UAVENV_HD double u53_int(uint32_t hi, uint32_t lo) {
     return (double)(((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+UAVENV_HD double u53(uint32_t hi, uint32_t lo) {
+    return fma((double)(hi >> 5), 1.0 / 134217728.0, (double)(lo >> 6) * (1.0 / 9007199254740992.0));
 }
 
 }  // namespace uavk

@@ -86,6 +86,18 @@ int main() {
                 if (uavk::lane_div(lane, uavk::lane_div_magic(U)) != lane / U) ++bad;
         std::printf("lane_div_mismatches 4096 %d 0\n", bad);
     }
+    {   // csrc/philox.h: the fma form of u53 against the integer form, bit for bit
+        std::mt19937_64 rng(2026);
+        const uint32_t edge[] = {0u, 1u, 31u, 32u, 63u, 64u, 0x7FFFFFFFu, 0x80000000u, 0xFFFFFFDFu, 0xFFFFFFE0u, 0xFFFFFFFFu};
+        long long bad = 0, total = 0;
+        for (uint32_t h : edge) for (uint32_t l : edge) { ++total; if (uavk::u53(h, l) != uavk::u53_int(h, l)) ++bad; }
+        for (int i = 0; i < 8000000; ++i) {
+            const uint64_t w = rng();
+            ++total;
+            if (uavk::u53((uint32_t)(w >> 32), (uint32_t)w) != uavk::u53_int((uint32_t)(w >> 32), (uint32_t)w)) ++bad;
+        }
+        std::printf("u53_mismatches %lld %lld 0\n", total, bad);
+    }
     run("rsqrt_dist2", [](double x) { return uavk::lm_rsqrt(x); }, [](long double x) { return 1.0L / std::sqrt(x); },
         [&](std::mt19937_64 &g) { return 25.0 * (double)(1 + g() % 2000000); }, n);
     // exact multiply-shift division used for the action digits: every divisor 2..9, dense + random + edge dividends

@@ -33,6 +33,8 @@ def test_lean_math_accuracy(tmp_path):
     n, worst, mean = rows["lm_div"]                    # rcp + Newton division on the two operand ranges the kernels feed it;
     assert n == 2000000 and worst <= 1.0 and mean < 0.3   # host seed is 24 bits, the device's v_rcp_f64 is better
     assert "rsqrt_dist2" in rows
+    total, bad, _ = rows["u53_mismatches"]              # csrc/philox.h: fma form of the 53-bit uniform == integer form, bit for bit
+    assert total == 8000121 and bad == 0
     total, bad, _ = rows["lane_div_mismatches"]        # csrc/intdiv.h: lane / U, the slot of a lane in the packed kernel
     assert total == 4096 and bad == 0
     total, bad, _ = rows["u32div_mismatches"]          # csrc/intdiv.h: exact a / d for d = 2..9 (action digits)

@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
   done
   wait; ls -la $OUT
 else
-  for round in 1 2 3; do
+  for round in ${UAVENV_AB_ROUNDS:-1 2 3}; do
     for v in "${VARIANTS[@]}"; do
       name=${v%%:*}
       UAVENV_LIB=$OUT/libuavenv_$name.so python3 $R/bench.py --steps 1500 --warmup 100 --no-cpu-baseline "${@:2}" 2>/dev/null | tail -1 | \
