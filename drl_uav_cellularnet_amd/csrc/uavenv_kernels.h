@@ -464,29 +464,41 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
 
 // Best UAV: SINR_b = pg_b / (noise + sum_{j != b} pg_j) is strictly increasing in pg_b (the total is fixed),
 // so np.argmax over the dB values (channel.py:141) == first maximum of pg.
+// best_pg returns pg[best] (the scan holds it anyway, so the caller need not select it again by index).
 template <int BT, bool FAST>
-__device__ __forceinline__ int argmax_pg(const KParams &p, const double pg[BT]) {
+__device__ __forceinline__ int argmax_pg(const KParams &p, const double pg[BT], double &best_pg) {
     const int B = uav_count<BT, FAST>(p.B);
     int best = 0;
     double bp = pg[0];
 #pragma unroll
     for (int b = 1; b < BT; ++b)
         if (b < B && pg[b] > bp) { bp = pg[b]; best = b; }
+    best_pg = bp;
     return best;
 }
 
 // 10*log10(S/(N+I)) for UAV x (channel.py:259-268); interference = the OTHER UAVs summed in index order,
 // never total - self (cancellation).  Only two of the B values are ever consumed: best and serving.
+// px = pg[x], supplied by the caller.  The masked sum is an fma with m in {0.0, 1.0}: pg*1 + interf rounds exactly like
+// interf + pg and pg*0 + interf is interf, so the value is that of `interf += (j != x) ? pg[j] : 0.0`; choosing between 0.0
+// and 1.0 takes one v_cndmask (their low words are both zero) where choosing between 0.0 and pg[j] takes two.
 template <int BT, bool FAST>
-__device__ __forceinline__ double sinr_db(const KParams &p, const HotConst &H, const LeanCoef &C, const double pg[BT], int x) {
+__device__ __forceinline__ double sinr_db_px(const KParams &p, const HotConst &H, const LeanCoef &C, const double pg[BT], int x, double px) {
     const int B = uav_count<BT, FAST>(p.B);
-    double interf = 0.0, px = 0.0;
+    double interf = 0.0;
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-        interf += (j != x && j < B) ? pg[j] : 0.0;
-        px = (j == x) ? pg[j] : px;
+        const double m = (j != x && j < B) ? 1.0 : 0.0;
+        interf = fma(pg[j], m, interf);
     }
     return H.db_per_ln * lm_logc(lm_div(px, H.noise + interf), C);   // 10*log10(x) = (10/ln 10) * ln x; both operands normal
+}
+template <int BT, bool FAST>
+__device__ __forceinline__ double sinr_db(const KParams &p, const HotConst &H, const LeanCoef &C, const double pg[BT], int x) {
+    double px = 0.0;
+#pragma unroll
+    for (int j = 0; j < BT; ++j) px = (j == x) ? pg[j] : px;
+    return sinr_db_px<BT, FAST>(p, H, C, pg, x, px);
 }
 
 // bestBS_buf push + handover decision for one UE (channel.py:148-167).  r0..r2 = FIFO rows, oldest first.
@@ -775,8 +787,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     if (MODE != MODE_WARMUP) {
         double pg[BT];
         rx_power<BT, PLC, FAST, FAST && has_mobility(MODE)>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, q0, q1, pg);
-        const int best = argmax_pg<BT, FAST>(p, pg);
-        const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
+        double best_pg;
+        const int best = argmax_pg<BT, FAST>(p, pg, best_pg);
+        const double bestS = sinr_db_px<BT, FAST>(p, H, C, pg, best, best_pg);
         if (is_reset(MODE)) {
             // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
             cur = bestS;
@@ -954,8 +967,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
 
             double pg[BT];
             { const U4 z = {0u, 0u, 0u, 0u}; rx_power<BT, PLC, FAST, false>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, z, z, pg); }
-            const int best = argmax_pg<BT, FAST>(p, pg);
-            const double bestS = sinr_db<BT, FAST>(p, H, C, pg, best);
+            double best_pg;
+            const int best = argmax_pg<BT, FAST>(p, pg, best_pg);
+            const double bestS = sinr_db_px<BT, FAST>(p, H, C, pg, best, best_pg);
             if (is_reset(MODE)) {
                 const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
                 if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
