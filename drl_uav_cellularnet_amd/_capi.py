@@ -42,6 +42,7 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
+ABI_VERSION = 2   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
 STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
@@ -98,7 +99,7 @@ def load():
     lib.uavenv_set_state.argtypes = [_P, _P, C.c_int, _P]
     lib.uavenv_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.uavenv_philox4x32_10.restype = None
-    if lib.uavenv_abi_version() != 2:
+    if lib.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError("libuavenv.so ABI version mismatch")
     _lib = lib
     return lib

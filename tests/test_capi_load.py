@@ -26,6 +26,17 @@ def test_header_symbols_are_exported():
     assert set(names) == set(_capi.EXPORTS)
 
 
+def test_graft_entry_build_runs_to_completion():
+    """__graft_entry__.build() is the driver's "does it build" gate: it must return normally (forced hipcc rebuild of both
+    libraries, oracle via make, import, ABI checks).  A stale literal in it once raised AFTER everything had compiled."""
+    import __graft_entry__ as g
+
+    g.build()
+    for lib in ("libuavenv.so", "libuavagent.so"):
+        assert os.path.isfile(os.path.join(ROOT, "drl_uav_cellularnet_amd", "lib", lib))
+    assert os.path.isfile(os.path.join(ROOT, "oracle", "libuavenv_oracle.so"))
+
+
 def test_agent_library_exports_its_header():
     """libuavagent.so (include/uavagent.h, the learner's sparse first layer): built, loadable, every declared symbol exported;
     argument checks answer before any HIP call."""
@@ -52,7 +63,9 @@ def test_host_side_calls_without_gpu():
     from drl_uav_cellularnet_amd import _capi
 
     lib = _capi.load()
-    assert lib.uavenv_abi_version() == 2
+    header = open(os.path.join(ROOT, "include", "uavenv.h")).read()
+    declared = int(re.search(r"#define\s+UAVENV_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.uavenv_abi_version() == declared == _capi.ABI_VERSION      # header, library and binding agree
     cfg = _capi.make_config(4, 40, 100)
     assert [cfg.bs_init_xy[b][0] for b in range(4)] == [25, 25, 75, 75]  # mobile_env.py:49
     assert [cfg.bs_init_xy[b][1] for b in range(4)] == [25, 75, 25, 75]  # mobile_env.py:50
