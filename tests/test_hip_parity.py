@@ -143,6 +143,8 @@ PHILOX_SHAPES = [
                                                # MOVED coordinate is range-checked (:221-253), so they may slide along a wall
     (7, 33, 64, 8, 40, {"n_act": 9}),          # checked variant (B = 7 < BT = 8)
     (16, 200, 100, 4, 12, {"n_act": 9}),       # multi-pass, 9^16 needs the 64-bit digit path
+    (4, 20, 100, 6, 2100, {}),                 # a whole episode and beyond: `done` turns on at step 2000 and stays on (no auto-reset),
+                                               # ~20 aggregation phase changes, hundreds of group arrivals, masked reset at step 1050
     # the extremes check_config() allows
     (2, 4096, 100, 2, 3, {}),                  # n_ue at its maximum: 64 passes, 64-word outage mask per env
     (4, 1000, 100, 3, 4, {}),                  # 16 passes, last one with 40 of 64 lanes
