@@ -102,8 +102,10 @@ def _bias_grad(g):
 
 def _table_grad(g, idx, n_rows):
     o2b, size, max_idx = _bags(idx.shape[0], idx.shape[1], idx.device)
-    return torch.ops.aten._embedding_bag_dense_backward(g.contiguous(), idx.reshape(-1), o2b, size, max_idx, n_rows, False, 0,
-                                                        None, -1)
+    flat = idx.reshape(-1)
+    keep = (flat >= 0).to(g.dtype)                # -1 = "no row" (agent.obs_to_indices): no gradient, as in first_layer_reference
+    return torch.ops.aten._embedding_bag_dense_backward(g.contiguous(), flat.clamp(min=0), o2b, size, max_idx, n_rows, False, 0,
+                                                        keep, -1)
 
 
 class _SparseRowsSum(torch.autograd.Function):

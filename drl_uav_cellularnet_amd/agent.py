@@ -36,14 +36,21 @@ def obs_to_indices(obs, grid_n, n_bs):
     srv = obs["serving"].long()
     ue_idx = (1 + srv) * (G * G) + ue[..., 0] * G + ue[..., 1]
     bs_idx = bs[..., 0] * G + bs[..., 1]
+    # A walker exactly on x == G or y == G (measure zero; the reference raises IndexError there) has no cell in
+    # the G x G planes: its entry becomes -1 = "no row", as obs_cell() does for the dense tensor, instead of aliasing the next
+    # row / plane.  Both first-layer implementations skip negative indices.
+    ue_ok = ((ue >= 0) & (ue < G)).all(dim=-1)
+    ue_idx = torch.where(ue_ok, ue_idx, torch.full_like(ue_idx, -1))
     return torch.cat([bs_idx, ue_idx], dim=-1)          # [N, B + U]; duplicates add, like the count map
 
 
 def first_layer_reference(idx, w_a, b_a, w_c=None, b_c=None):
     """The sparse first layer in plain PyTorch: (h_a, h_c), h = sum_k W[idx[:, k]] + b.  Reference implementation of the HIP
     kernel (tests/test_agent_kernel_gpu.py) and the path CPU tensors take."""
-    ha = F.embedding_bag(idx, w_a, mode="sum") + b_a
-    hc = None if w_c is None else F.embedding_bag(idx, w_c, mode="sum") + b_c
+    keep = (idx >= 0).to(w_a.dtype)                     # -1 = "no row" (obs_to_indices): weight 0
+    safe = idx.clamp(min=0)
+    ha = F.embedding_bag(safe, w_a, per_sample_weights=keep, mode="sum") + b_a
+    hc = None if w_c is None else F.embedding_bag(safe, w_c, per_sample_weights=keep, mode="sum") + b_c
     return ha, hc
 
 
@@ -197,7 +204,7 @@ class A2CRunner:
     (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536):
+                 update_chunk=65536, first_state="obs"):
         self.env = env
         self.dev = env.device
         self.G, self.B = env.grid_n, env.nBS
@@ -207,8 +214,15 @@ class A2CRunner:
         self.T, self.gamma, self.beta = int(rollout), float(gamma), float(beta)
         self.update_chunk = int(update_chunk)
         self.gen = torch.Generator(device=self.dev).manual_seed(int(seed) + 1000 * int(env.env_id_base + 1))
-        self.idx = obs_to_indices(env.observation(), self.G, self.B)   # the reference starts from env.state (zeros,
-        self.ep_r = torch.zeros(env.n_envs, device=self.dev)           # a2c_single_thread.py:155); we use the real obs
+        # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
+        # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
+        # every index is -1 = "no row" and the first layer returns its bias.
+        if first_state not in ("obs", "zeros"):
+            raise ValueError("first_state must be 'obs' or 'zeros'")
+        self.idx = obs_to_indices(env.observation(), self.G, self.B)
+        if first_state == "zeros":
+            self.idx = torch.full_like(self.idx, -1)
+        self.ep_r = torch.zeros(env.n_envs, device=self.dev)
         self.running_r = None                                          # GLOBAL_RUNNING_R EMA, :169-172
         self.stats = {}
 

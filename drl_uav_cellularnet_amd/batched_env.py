@@ -102,6 +102,8 @@ class BatchedMobiEnv:
 
     # ---- injected randomness (parity tests) --------------------------------------------------------
     def _dev64(self, a, shape):
+        if not isinstance(a, torch.Tensor):
+            a = np.ascontiguousarray(a, dtype=np.float64)   # (a read-only broadcast view would make torch.as_tensor warn)
         t = torch.as_tensor(a, dtype=torch.float64).reshape(shape)
         return t.to(self.device).contiguous()
 

@@ -20,6 +20,12 @@ thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 __device__ __forceinline__ void add4(float4 &s, const float4 &v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+// s += v * w with w in {0.0f, 1.0f} held in an SGPR: one v_fmac per component, like the add it replaces; v * 1 + s rounds exactly
+// like s + v, and v * 0 + s is s for the finite table entries (a skipped row still costs its read, of row 0, but adds nothing).
+__device__ __forceinline__ void fma4(float4 &s, const float4 &v, float w) {
+    s.x = __builtin_fmaf(v.x, w, s.x); s.y = __builtin_fmaf(v.y, w, s.y); s.z = __builtin_fmaf(v.z, w, s.z); s.w = __builtin_fmaf(v.w, w, s.w);
+}
+__device__ __forceinline__ float lane_weight(float w, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k)); }
 
 // KT > 0: K known at compile time (24 = 4 UAV + 20 UE, 44 = 4 + 40), so the row loop unrolls by UNR with no remainder --
 // v_readlane is a convergent operation and hipcc will not unroll a loop around it when the trip count is a run-time value.
@@ -37,8 +43,10 @@ __global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__res
     if (m >= M) return;
     long long mine = 0;
     if (lane < K) mine = idx[m * K + lane];
-    // Memory safety on a shared GPU: an index outside the table is clamped, never dereferenced (include/uavagent.h).
-    mine = mine < 0 ? 0 : (mine >= n_rows ? n_rows - 1 : mine);
+    // An index outside [0, n_rows) means "no row" (agent.obs_to_indices writes -1 for a walker off the grid, and an all -1 list is
+    // the reference's all-zero first state): it contributes nothing and is never dereferenced (include/uavagent.h).
+    const float wgt = (mine >= 0 && mine < n_rows) ? 1.f : 0.f;
+    mine = (wgt != 0.f) ? mine : 0;
     const uint32_t row_bytes = (uint32_t)H4 * 16u;
     const uint32_t my_row_off = (uint32_t)mine * row_bytes;          // < 4 GiB: checked by the host entry point
     // Every lane loads UNCONDITIONALLY: a conditional float4 load is split by hipcc into four exec-masked dword loads with a
@@ -59,13 +67,18 @@ __global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__res
                 if (TWO) vc[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wc) + off);
             }
 #pragma unroll
-            for (int j = 0; j < UNR; ++j) { add4(sa, va[j]); if (TWO) add4(sc, vc[j]); }   // k ascending
+            for (int j = 0; j < UNR; ++j) {                            // k ascending
+                const float w = lane_weight(wgt, k0 + j);
+                fma4(sa, va[j], w);
+                if (TWO) fma4(sc, vc[j], w);
+            }
         }
     } else {
         for (int k = 0; k < K; ++k) {
             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, k) + lane_off;
-            add4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wa) + off));
-            if (TWO) add4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wc) + off));
+            const float w = lane_weight(wgt, k);
+            fma4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wa) + off), w);
+            if (TWO) fma4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wc) + off), w);
         }
     }
     if (!on) return;

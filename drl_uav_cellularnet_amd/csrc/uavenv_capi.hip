@@ -31,6 +31,8 @@ struct uavenv {
     long long *act_pow_dev;
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
+    const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
+    int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
 };
@@ -151,10 +153,12 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || device < 0 || device >= n_dev)
         return fail(UAVENV_E_NODEVICE, "create: no HIP device " + std::to_string(device));
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);   // the caller's current device is restored on every return path
     uavenv *h = new (std::nothrow) uavenv();
     if (!h) return fail(UAVENV_E_NOMEM, "create: host allocation failed");
     h->cfg = *cfg; h->N = n_envs; h->device = device; h->seed = seed; h->env_id_base = env_id_base;
+    h->force_pin = -1;
+    if (const char *f = std::getenv("UAVENV_FORCE_PIN")) h->force_pin = (f[0] == '1') ? 1 : 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
@@ -170,17 +174,6 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     L.total_bytes = SO.total;
     L.ue_pos = SO.ue_pos; L.ue_aux = SO.ue_aux; L.grp = SO.grp; L.env = SO.env; L.bs_xy = SO.bs_xy; L.out_bits = SO.out_bits;
 
-    hipError_t e = hipMalloc((void **)&h->blob, L.total_bytes);
-    if (e != hipSuccess) { delete h; return fail(UAVENV_E_NOMEM, std::string("create: hipMalloc state: ") + hipGetErrorString(e)); }
-    e = hipMalloc((void **)&h->bs_init_dev, sizeof(int32_t) * 2 * UAVENV_MAX_BS);
-    if (e != hipSuccess) { (void)hipFree(h->blob); delete h; return fail(UAVENV_E_NOMEM, "create: hipMalloc bs_init"); }
-    e = hipMalloc((void **)&h->act_pow_dev, sizeof(long long) * UAVENV_MAX_BS);
-    if (e != hipSuccess) {
-        (void)hipFree(h->blob); (void)hipFree(h->bs_init_dev); delete h;
-        return fail(UAVENV_E_NOMEM, "create: hipMalloc act_pow");
-    }
-    (void)hipMemset(h->blob, 0, L.total_bytes);
-    (void)hipMemcpy(h->bs_init_dev, cfg->bs_init_xy, sizeof(int32_t) * 2 * UAVENV_MAX_BS, hipMemcpyHostToDevice);
     // act_pow[b] = n_act^(B-1-b): digit of UAV b in the joint action, most significant first
     // (Decimal_to_Base_N, ue_mobility.py:310-336).  check_config() has verified n_act^B fits in int64.
     long long act_pow[UAVENV_MAX_BS];
@@ -188,20 +181,30 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     long long pw = 1;
     for (int b = cfg->n_bs - 1; b >= 0; --b) { act_pow[b] = pw; pw *= cfg->n_act; }
     const long long n_joint = pw;  // n_act^B = action_space_dim (mobile_env.py:104)
-    (void)hipMemcpy(h->act_pow_dev, act_pow, sizeof(act_pow), hipMemcpyHostToDevice);
-    {   // group of every walker (ue_mobility.py:417-426 g_ref), padded so that idle lanes read in range
-        const size_t n_gid = U < 64 ? 64 : U;
-        std::string gid(n_gid, '\0');
+    // group of every walker (ue_mobility.py:417-426 g_ref), padded so that idle lanes read in range
+    const size_t n_gid = U < 64 ? 64 : U;
+    std::string gid(n_gid, '\0');
+    {
         size_t w = 0;
         for (int g = 0; g < cfg->n_groups; ++g)
             for (int i = 0; i < cfg->group_size[g]; ++i) gid[w++] = (char)g;
-        e = hipMalloc((void **)&h->gid_dev, n_gid);
-        if (e != hipSuccess) {
-            (void)hipFree(h->blob); (void)hipFree(h->bs_init_dev); (void)hipFree(h->act_pow_dev); delete h;
-            return fail(UAVENV_E_NOMEM, "create: hipMalloc gid table");
-        }
-        (void)hipMemcpy(h->gid_dev, gid.data(), n_gid, hipMemcpyHostToDevice);
     }
+    // Allocations and uploads: any failure frees what exists and reports; a handle is never returned half-initialised.
+    auto bail = [&](int code, const char *what, hipError_t err) {
+        const std::string msg = std::string("create: ") + what + ": " + hipGetErrorString(err);
+        uavenv_destroy(h);
+        return fail(code, msg);
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&h->blob, L.total_bytes)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc state", e);
+    if ((e = hipMalloc((void **)&h->bs_init_dev, sizeof(int32_t) * 2 * UAVENV_MAX_BS)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc bs_init", e);
+    if ((e = hipMalloc((void **)&h->act_pow_dev, sizeof(long long) * UAVENV_MAX_BS)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc act_pow", e);
+    if ((e = hipMalloc((void **)&h->gid_dev, n_gid)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc gid table", e);
+    if ((e = hipMemset(h->blob, 0, L.total_bytes)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemset state", e);
+    if ((e = hipMemcpy(h->bs_init_dev, cfg->bs_init_xy, sizeof(int32_t) * 2 * UAVENV_MAX_BS, hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(UAVENV_E_HIP, "hipMemcpy bs_init", e);
+    if ((e = hipMemcpy(h->act_pow_dev, act_pow, sizeof(act_pow), hipMemcpyHostToDevice)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemcpy act_pow", e);
+    if ((e = hipMemcpy(h->gid_dev, gid.data(), n_gid, hipMemcpyHostToDevice)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemcpy gid table", e);
 
     KParams &k = h->kp;
     std::memset(&k, 0, sizeof(k));
@@ -252,7 +255,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
 
 extern "C" void uavenv_destroy(uavenv_t *h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);   // runs from __del__ at GC time: must not move the caller's current device
     (void)hipFree(h->blob);
     (void)hipFree(h->bs_init_dev);
     (void)hipFree(h->act_pow_dev);
@@ -322,7 +325,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     // 8.67 vs 9.20, 2.0 9.29 vs 9.77, 2.67 12.87 vs 12.08, 4.0 15.87 vs 14.98: two co-resident waves profit from constants that
     // are not re-read through the scalar path; a lone wave only pays for materialising them; beyond two, occupancy wins.
     bool pin = fast && (waves >= h->n_simd) && (waves <= 2 * h->n_simd);
-    if (const char *f = std::getenv("UAVENV_FORCE_PIN")) pin = fast && (f[0] == '1');   // experiments only
+    if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
         if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true>), dim3(grid), blk, 0, s, PK_ARGS);     \
@@ -435,12 +438,15 @@ extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     hipLaunchKernelGGL((obs_cells_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        k.N, k.U, k.B, k.G, k.bs_xy, k.ue_aux, h->obs_prev_dev, obs_dev);
     HIP_TRY(hipGetLastError());
+    h->obs_last_dev = obs_dev;
     return UAVENV_OK;
 }
 
 extern "C" int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense_update: null handle or buffer");
-    if (!h->obs_prev_dev) return fail(UAVENV_E_INVALID, "obs_dense_update: call uavenv_obs_dense on this buffer first");
+    if (!h->obs_prev_dev || h->obs_last_dev != obs_dev)   // deltas against another buffer's cell list would corrupt it silently
+        return fail(UAVENV_E_INVALID, "obs_dense_update: obs_dev is not the buffer the last uavenv_obs_dense call of this handle wrote; "
+                                      "call uavenv_obs_dense on it first");
     DeviceGuard guard(h->device);
     const KParams &k = h->kp;
     const long long total = k.N * (k.U + k.B);

@@ -23,8 +23,9 @@ const char *uavagent_last_error(void);
 /* out_a[m, :] = sum_k w_a[idx[m, k], :] + bias_a   (k ascending, fp32; bias added last, like embedding_bag(...) + b)
  * and, when w_c != NULL, the same for (w_c, bias_c, out_c) with the SAME indices: actor and critic read one index list.
  * All pointers are device pointers on the current device; rows are contiguous (row stride = h floats).
- *   idx   int64 [m_rows, k]   each in [0, n_rows).  An index outside that range is CLAMPED into it, never dereferenced and not
- *                             reported (a faulting kernel can reset a shared GPU host; torch's embedding_bag asserts instead)
+ *   idx   int64 [m_rows, k]   each in [0, n_rows), or outside that range (by convention -1) = "no row": the entry adds nothing and
+ *                             is never dereferenced (a faulting kernel can reset a shared GPU host).  An all -1 list yields the
+ *                             bias: the reference's all-zero first state (a2c_single_thread.py:155)
  *   w_*   f32   [n_rows, h]   h % 4 == 0, 4 <= h <= 256, 16-byte aligned, n_rows * h * 4 < 4 GiB
  *   bias_* f32  [h] or NULL;  out_* f32 [m_rows, h], 16-byte aligned
  *   1 <= k <= 64.  `stream` is a hipStream_t (0 = the null stream).  Asynchronous. */

@@ -129,7 +129,8 @@ int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue
                       const UavEnvInject *inj, const UavEnvOut *out, void *stream);
 /* Same tensor, updated IN PLACE: obs_dev must still hold what the previous uavenv_obs_dense / uavenv_obs_dense_update
  * call of this handle wrote into it (the handle remembers those <= U+B cells per env); only cells that changed are
- * touched (-1 at the old cell, +1 at the new one).  First use on a buffer: call uavenv_obs_dense once. */
+ * touched (-1 at the old cell, +1 at the new one).  First use on a buffer: call uavenv_obs_dense once.  The handle remembers
+ * which buffer that was: any other obs_dev is refused with UAVENV_E_INVALID (its deltas would corrupt it silently). */
 int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream);
 /* MobiEnvironment.reset (and the constructor) in read_trace mode (mobile_env.py:85-89,128-131): UE cells come from
  * ue_xy_in_dev [N,U,2] (trace row 0), no mobility tick; UAVs to their start cells, LTEChannel.reset, step_n = 0. */

@@ -99,16 +99,26 @@ def test_acnet_cuda_equals_reference_layers():
     torch.testing.assert_close(net.critic_only(idx), v_ref, rtol=1e-5, atol=1e-6)
 
 
-def test_out_of_range_indices_are_clamped_not_dereferenced():
+def test_out_of_range_indices_are_skipped_not_dereferenced():
+    """An index outside [0, S) is "no row": it adds nothing (include/uavagent.h); first_layer_reference agrees for -1, and a list
+    of -1 only gives the bias (the reference's all-zero first state, a2c_single_thread.py:155)."""
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
+    from drl_uav_cellularnet_amd.agent import first_layer_reference, sparse_first_layer
 
     S, H = 1000, 200
     w = (torch.randn(S, H) * 0.1).cuda()
-    idx = torch.tensor([[-5, 3, S + 7] + [1] * 21, [2 ** 40, -2 ** 40, 0] + [2] * 21], dtype=torch.int64, device="cuda")
-    out = A.sparse_rows_sum(idx, w, None)
-    ref = w[idx.clamp(0, S - 1)].sum(dim=1)
+    b = (torch.randn(H) * 0.1).cuda()
+    idx = torch.tensor([[-5, 3, S + 7] + [1] * 21, [2 ** 40, -2 ** 40, 0] + [2] * 21, [-1] * 24], dtype=torch.int64, device="cuda")
+    out = A.sparse_rows_sum(idx, w, b)
+    ok = ((idx >= 0) & (idx < S)).float().unsqueeze(-1)
+    ref = (w[idx.clamp(0, S - 1)] * ok).sum(dim=1) + b
     torch.testing.assert_close(out, ref, rtol=FWD_RTOL, atol=FWD_ATOL)
+    assert torch.equal(out[2], b)
+    neg = torch.tensor([[-1, 3, 5] + [1] * 21, [-1] * 24], dtype=torch.int64, device="cuda")
+    ha, _ = sparse_first_layer(neg, w, b)
+    ra, _ = first_layer_reference(neg, w, b)
+    torch.testing.assert_close(ha, ra, rtol=FWD_RTOL, atol=FWD_ATOL)
 
 
 def test_bad_arguments_raise():
