@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/s of the HIP hot path (BASELINE.json metric), one JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--launch graph|eager|many] [--mode env|a2c]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one batched MobiEnvironment.step() over all envs of a rank = ONE kernel launch.
-Workload at N=1: BASELINE.json configs[1] -- 4096 envs, 4 UAV x 20 UE (groups 5,5,5,5), G=100, on-device
-Philox randomness, uniform random joint actions resident in HBM before the timed region, compact
-outputs only (no dense observation).  N>1: the same workload per rank (weak scaling); env instances are
-independent, so there is NO data-path collective -- only the barrier/max-reduce of the timing.
+A "step" = one batched MobiEnvironment.step() over all envs of a rank (mobile_env.py:150-194).
+Workload at N=1: BASELINE.json configs[1] -- 4096 envs, 4 UAV x 20 UE (groups 5,5,5,5), G=100, on-device Philox randomness,
+uniform random joint actions resident in HBM before the timed region, compact outputs only (no dense observation).
+N>1: the same workload per rank (weak scaling); env instances are independent, so there is NO data-path collective in the
+env bench -- only the barrier / max-reduce of the timing.  `python bench.py --gpus N` WITHOUT a launcher starts its own N
+ranks (one process per GPU, spawned before anything touches the GPU) and fails loudly if fewer than N joined.
+
+--launch  how the K step() launches reach the GPU (the kernel is the same single-step kernel for graph / eager):
+            graph  (default) hipGraph replay of chunks of <= 100 captured uavenv_step launches: one kernel per step, no per-step
+                   host cost.  From Python a launch costs ~8 us of host time (tools/host_floor.py), as much as the 4096-env kernel.
+            eager  one ctypes call per step (round 1's bench)
+            many   uavenv_step_many: <= 100 steps per launch, state carried in registers (open-loop callers only)
+--mode a2c  BASELINE configs[2] (N=1) / configs[3] (N=8): 8192 envs per GPU, MLP actor-critic, 50-step rollouts, one update per
+            rollout with ONE flat RCCL all-reduce of the 80.8 MB gradient inside the timed region (a2c_single_thread.py:107-133).
+            The default (env) run appends the same measurement as the "a2c" object of its line unless --no-a2c.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -23,7 +34,10 @@ if ROOT not in sys.path:
 
 N_BS, N_UE, GRID, GROUPS = 4, 20, 100, [5, 5, 5, 5]
 SEED = 0x5EED
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIMD_ISSUE_HZ = 2.4e9 / 4.0   # one VALU wave-instruction per 4 cycles per SIMD at 2.4 GHz (MI355X_MICROARCH.md cycle table)
+CHUNK = 100                   # steps per captured graph / per uavenv_step_many launch (divides MAXSTEP = 2000)
+A2C_ENVS, A2C_ROLLOUT = 8192, 50
 
 
 def algorithmic_bytes_per_env_step(U, B, Gr):
@@ -40,12 +54,13 @@ def transcendental_evals_per_env_step(U, B):
     return U * (4 + 3 * hb + 2 * B)
 
 
-STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true>"   # rocprofv3 name (template part) of the step kernel of this workload
+STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true, false>"   # rocprofv3 name (template part) of the single-step kernel of this workload
 
 
-def measured_traffic(envs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_current.json), or None when
-    that file describes another kernel / batch size.  bench.py cannot run the profiler on itself."""
+def committed_counters(envs):
+    """Per-launch PMC figures of the step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
+    cannot run the profiler on itself, so these are constants of the profiled build, labelled as such in the line.  None when
+    that file describes another kernel / batch size."""
     path = os.path.join(ROOT, "profiles", "traffic_current.json")
     try:
         with open(path) as f:
@@ -54,30 +69,47 @@ def measured_traffic(envs):
         return None
     if t.get("kernel") != STEP_KERNEL or t.get("envs") != envs or t.get("n_ue") != N_UE or t.get("n_bs") != N_BS:
         return None
-    return int(t["fetch_size_bytes_raw"]) + int(t["write_size_bytes_raw"])
+    return t
 
 
-def cpu_baseline(target_seconds=15.0):
-    """Times the CPU oracle (oracle/, kind 'port': scalar C restatement of the reference's step())
-    on a bounded sample of the same workload, one shard per host thread."""
+def cpu_baseline(target_seconds=12.0):
+    """the CPU oracle (oracle/, kind 'port': scalar float64 C restatement of the reference's step(),
+    same loop structure as channel.py:249-269) timed on the box's host cores on a bounded sample of the same workload:
+    (a) ONE env on ONE core -- the like-for-like stand-in for one reference process (the reference itself, NumPy, measured
+    ~670 steps/s at this shape in the build container); (b) one 64-env shard per thread on all usable cores."""
     import numpy as np
 
     from oracle import oracle as O
 
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    per = 64
     cfg = O.make_config(N_BS, N_UE, GRID, groups=GROUPS)
-    envs = [O.OracleEnv(cfg, per, seed=SEED, env_id_base=i * per) for i in range(cores)]
+    rs = np.random.RandomState(1234)
+    # (a) N = 1, single core
+    one = O.OracleEnv(cfg, 1, seed=SEED)
+    one.construct()
+    acts1 = rs.randint(0, 625, size=(4096, 1)).astype(np.int64)
+    n1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds / 4.0:
+        for t in range(512):
+            one.step(acts1[(n1 + t) % 4096])
+        n1 += 512
+    single = n1 / (time.perf_counter() - t0)
+    # (b) all usable cores: what this process may run on (cgroup / affinity), not what the host has
+    host_cpus = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cpus
+    threads = max(1, min(usable, 64))
+    per = 64
+    envs = [O.OracleEnv(cfg, per, seed=SEED, env_id_base=i * per) for i in range(threads)]
     for e in envs:
         e.construct()
-    rs = np.random.RandomState(1234)
     acts = rs.randint(0, 625, size=(256, per)).astype(np.int64)
-    # calibrate on one thread, then size the sample for ~target_seconds
     t0 = time.perf_counter()
     for t in range(20):
         envs[0].step(acts[t])
     dt = (time.perf_counter() - t0) / 20
-    steps = int(max(50, min(60000, target_seconds / max(dt, 1e-9))))
+    steps = int(max(50, min(60000, 0.75 * target_seconds / max(dt, 1e-9))))
 
     def work(env):
         for t in range(steps):
@@ -90,107 +122,402 @@ def cpu_baseline(target_seconds=15.0):
     for t in th:
         t.join()
     el = time.perf_counter() - t0
-    return {"value": cores * per * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d envs x %d steps of oracle step() (4 UAV x 20 UE, G=100, Philox), %.1f s"
-                      % (cores, per, steps, el)}
+    return {"value": threads * per * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "host_cpus": host_cpus, "usable_cpus": usable,
+            "single_core_n1": {"value": single, "unit": "env-steps/s", "cores": 1,
+                               "sample": "1 env x %d steps of oracle step() on one thread" % n1},
+            "sample": "%d threads (one per usable CPU, max 64) x %d envs x %d steps of oracle step() (4 UAV x 20 UE, G=100, "
+                      "Philox), %.1f s" % (threads, per, steps, el)}
 
 
-def main():
+# ----------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.
+    Runs in a parent that has not touched the GPU (no torch import, no HIP call); rank 0's stdout carries the JSON line.
+    Exit code: 0 only if EVERY rank exited 0 -- a rank that never joined makes the others fail in init / the rank census."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UAVENV_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("UAVENV_BENCH_TIMEOUT", "1500"))
+    pending = list(enumerate(procs))
+    while pending:
+        for r, p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove((r, p))
+                if code != 0:
+                    print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
+                    rc = rc or code or 1
+        if rc and pending:              # one rank failed: the others would wait in a collective until the timeout
+            time.sleep(5.0)
+            for _, p in pending:
+                if p.poll() is None:
+                    p.terminate()
+            for _, p in pending:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if time.time() > deadline:
+            print("bench.py: timeout, terminating the ranks", file=sys.stderr)
+            for _, p in pending:
+                p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
+    ap.add_argument("--mode", choices=("env", "a2c"), default="env")
+    ap.add_argument("--launch", choices=("graph", "eager", "many"), default="graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-a2c", action="store_true", help="env mode: skip the appended A2C / gradient all-reduce measurement")
+    ap.add_argument("--no-alt", action="store_true", help="env mode: skip the secondary eager / step_many measurements")
+    ap.add_argument("--a2c-rollouts", type=int, default=4, help="timed rollouts (+1 untimed) of the appended A2C measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
-                    "rehearse the multi-rank path with several ranks sharing one GPU)")
+                    "rehearse the multi-rank path with several ranks sharing one GPU, or with --rehearse-launcher on CPU)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even at "
                     "world size 1 (exercises the RCCL init / barrier / max-reduce path on a one-GPU box)")
+    ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU work at all: ranks rendezvous (gloo), run the rank "
+                    "census / barrier / max-reduce and rank 0 prints a line marked rehearsal (value null).  CPU test of the launcher")
     ap.add_argument("--n-bs", type=int, default=N_BS, help="secondary measurements only (default = BASELINE workload)")
     ap.add_argument("--n-ue", type=int, default=N_UE, help="secondary measurements only (default = BASELINE workload)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def init_dist(args, rank, local_rank, world):
+    """-> (dist module or None, device index).  One process per GPU; backend nccl = RCCL over xGMI."""
+    if not (world > 1 or args.force_dist):
+        return None, local_rank
+    import datetime
 
     import torch
+    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if args.force_device is not None:
+        local_rank = args.force_device
+    tmo = datetime.timedelta(seconds=300)
+    if args.rehearse_launcher:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        return dist, local_rank
+    torch.cuda.set_device(local_rank)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
+    return dist, local_rank
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        if args.force_device is not None:
-            local_rank = args.force_device
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
-    from drl_uav_cellularnet_amd import BatchedMobiEnv
-    from drl_uav_cellularnet_amd.sharding import max_over_ranks, shard_for_rank, whole_job_rate
+def rank_census(dist, dev):
+    """Number of ranks that actually take part in a reduction (sum of ones)."""
+    if dist is None:
+        return 1
+    import torch
 
-    E, K, W = args.envs, args.steps, args.warmup
-    env_id_base, _ = shard_for_rank(rank, world, E)   # rank r owns global envs [r*E, (r+1)*E): no env-path collective
-    n_bs, n_ue = args.n_bs, args.n_ue
-    baseline_shape = (n_bs, n_ue) == (N_BS, N_UE)
-    groups = GROUPS if baseline_shape else [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
-    env = BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=GRID, groups=groups, device=dev, seed=SEED,
-                         env_id_base=env_id_base)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    n_act = min(K + W, 512)  # action table resident in HBM, cycled
-    actions = torch.randint(0, min(env.action_space_dim, 2 ** 62), (n_act, E), generator=gen, dtype=torch.int64).to(dev)
-    max_step = int(env.cfg.max_step)
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
 
-    def run(n, start):
-        for t in range(start, start + n):
-            env.step(actions[t % n_act])
-            if (t + 1) % max_step == 0:  # the reference's callers reset on `done` (main.py:205-211)
+
+class EnvRun:
+    """K steps of the env workload in segments of <= CHUNK steps, reset() every MAXSTEP steps as the reference's callers do
+    (main.py:205-211).  Before each segment the next CHUNK action rows are copied from the resident pool into a tape the
+    graph / the multi-step kernel reads (3.3 MB device-to-device per 100 steps at 4096 envs)."""
+
+    def __init__(self, env, launch, pool):
+        import torch
+
+        self.env, self.launch, self.pool = env, launch, pool
+        self.tape = torch.empty((CHUNK, env.n_envs), dtype=torch.int64, device=env.device)
+        self.graphs = {}
+        self.many_out = {}
+        self.max_step = int(env.cfg.max_step)
+        self.t = 0            # steps since the last reset (the constructor's reset counts as one)
+        self.cursor = 0       # next pool row
+
+    def prepare(self, sizes):
+        """Capture / allocate for every segment length that will occur (outside the timed region; executes no step)."""
+        import torch
+
+        for n in sorted(set(sizes)):
+            if self.launch == "graph" and n not in self.graphs:
+                self.graphs[n] = self.env.capture_steps(self.tape[:n])
+            if self.launch == "many" and n not in self.many_out:
+                self.many_out[n] = {k: torch.empty((n,) + tuple(v.shape), dtype=v.dtype, device=v.device)
+                                    for k, v in self.env.out.items()}
+
+    def plan(self, n_steps, t0=None):
+        """Segment lengths for n_steps more steps, cut at reset boundaries: [(n, reset_after)]."""
+        t = self.t if t0 is None else t0
+        segs = []
+        while n_steps > 0:
+            n = min(CHUNK, n_steps, self.max_step - t)
+            t += n
+            n_steps -= n
+            segs.append((n, t == self.max_step))
+            if t == self.max_step:
+                t = 0
+        return segs
+
+    def run(self, n_steps):
+        env = self.env
+        P = self.pool.shape[0]
+        for n, reset_after in self.plan(n_steps):
+            if self.cursor + n > P:
+                self.cursor = 0
+            self.tape[:n].copy_(self.pool[self.cursor:self.cursor + n])
+            self.cursor += n
+            if self.launch == "graph":
+                self.graphs[n].replay()
+            elif self.launch == "many":
+                env.step_many(self.tape[:n], out=self.many_out[n], refresh_out=False)
+            else:
+                for t in range(n):
+                    env.step(self.tape[t])
+            self.t += n
+            if reset_after:
                 env.reset()
+                self.t = 0
 
-    run(W, 0)
+
+def timed(fn, dist, dev):
+    """barrier + synchronize on both sides, HIP events on the launch stream inside -> (wall seconds, gpu ms)."""
+    import torch
+
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(K, W)
+    fn()
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=dev if args.backend == "nccl" else None)  # slowest rank
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+
+def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank):
+    import torch
+
+    from drl_uav_cellularnet_amd.sharding import max_over_ranks
+
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    n_pool = max(CHUNK, min(((K + W + CHUNK - 1) // CHUNK) * CHUNK, 5 * CHUNK))    # action pool resident in HBM, cycled
+    pool = torch.randint(0, min(env.action_space_dim, 2 ** 62), (n_pool, env.n_envs), generator=gen, dtype=torch.int64).to(dev)
+    r = EnvRun(env, launch, pool)
+    sizes = [n for n, _ in r.plan(W)] + [n for n, _ in r.plan(K, t0=(r.t + W) % r.max_step)]
+    r.prepare(sizes)
+    r.run(W)
+    elapsed, gpu_ms = timed(lambda: r.run(K), dist, dev)
+    elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
+    return elapsed, gpu_ms
+
+
+def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollout_len=A2C_ROLLOUT):
+    """`rollouts` timed rollouts (after one untimed) of synchronous A2C: policy + sampling + env step per time step, then ONE
+    update over all T*N samples with one flat gradient all-reduce (RCCL when world > 1) and the TF1-semantics RMSProp step."""
+    import torch
+
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner, grad_allreduce_bytes
+    from drl_uav_cellularnet_amd.sharding import max_over_ranks, shard_for_rank, whole_job_rate
+
+    base, _ = shard_for_rank(rank, world, envs)
+    env = BatchedMobiEnv(envs, nBS=N_BS, nUE=N_UE, grid_n=GRID, groups=GROUPS, device=dev, seed=SEED, env_id_base=base)
+    runner = A2CRunner(env, rollout=rollout_len)
+    runner.train_rollout()                                         # untimed: allocator, rocBLAS / RCCL first use, graph capture
+    prof = {"collect": 0.0, "update": 0.0}
+
+    def go():
+        for _ in range(rollouts):
+            a = time.perf_counter()
+            batch = runner.collect()
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            runner.update(*batch)
+            torch.cuda.synchronize()
+            prof["collect"] += b - a
+            prof["update"] += time.perf_counter() - b
+
+    elapsed, _ = timed(go, dist, dev)
+    elapsed = max_over_ranks([elapsed], device=reduce_dev)[0]
+    n = envs * rollout_len * rollouts
+    st = runner.stats
+    return {"metric": "A2C end-to-end env steps/sec (policy + sampling + env step + update incl. gradient all-reduce)",
+            "value": whole_job_rate(n, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "envs_per_gpu": envs,
+            "rollout_len": rollout_len, "rollouts": rollouts, "ms_per_rollout": elapsed / rollouts * 1e3,
+            "collect_ms_per_rollout": prof["collect"] / rollouts * 1e3, "update_ms_per_rollout": prof["update"] / rollouts * 1e3,
+            "allreduce_ms_per_update": st.get("allreduce_ms"), "grad_allreduce_bytes": grad_allreduce_bytes(runner.net),
+            "allreduce": ("RCCL (nccl backend), one flat bucket per update" if (world > 1 and args.backend == "nccl")
+                          else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
+            "collect_launch": getattr(runner, "collect_launch", "eager"),
+            "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
+            "config": "8192 envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, 50-step rollouts, 1 update per rollout"}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args.gpus, argv))          # parent: spawns the ranks, never touches the GPU
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d: refusing to print a line for the wrong rank count" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+
+    if args.rehearse_launcher:                          # CPU-only rehearsal of spawn + rendezvous + census + reductions
+        import torch
+
+        from drl_uav_cellularnet_amd.sharding import max_over_ranks, shard_for_rank
+
+        dist, _ = init_dist(args, rank, local_rank, world)
+        n = rank_census(dist, None)
+        base, _ = shard_for_rank(rank, world, 4096)
+        t = max_over_ranks([float(rank + 1), float(base)], device=None)
+        if n != args.gpus:
+            sys.exit(3)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "value": None, "n_gpus": n, "max_rank_plus_1": t[0], "max_env_id_base": t[1],
+                              "launcher": "self" if os.environ.get("UAVENV_BENCH_CHILD") else "external"}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import torch
+
+    dist, dev_index = init_dist(args, rank, local_rank, world)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    reduce_dev = dev if (dist is not None and args.backend == "nccl") else None
+    n_ranks = rank_census(dist, reduce_dev)
+    if n_ranks != args.gpus:
+        print("bench.py: %d ranks reduced, --gpus %d" % (n_ranks, args.gpus), file=sys.stderr)
+        sys.exit(3)
+
+    if args.mode == "a2c":
+        envs = args.envs or A2C_ENVS
+        rollouts = max(1, args.steps // A2C_ROLLOUT) if args.steps != 2000 else 6
+        res = measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts)
+        if rank == 0:
+            line = {"metric": res["metric"], "value": res["value"], "unit": "env-steps/s", "n_gpus": n_ranks,
+                    "steps": rollouts * A2C_ROLLOUT, "warmup": A2C_ROLLOUT, "ms_per_step": res["ms_per_rollout"] / A2C_ROLLOUT,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 env / f32 learner",
+                    "data": "synthetic", "config": {"workload": res["config"], "envs_per_gpu": envs,
+                                                    "parallelism": "env-shard x%d + grad all-reduce" % world}, "a2c": res}
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.sharding import shard_for_rank, whole_job_rate
+
+    E, K, W = args.envs or 4096, args.steps, args.warmup
+    env_id_base, _ = shard_for_rank(rank, world, E)   # rank r owns global envs [r*E, (r+1)*E): no env-path collective
+    n_bs, n_ue = args.n_bs, args.n_ue
+    baseline_shape = (n_bs, n_ue) == (N_BS, N_UE)
+    groups = GROUPS if baseline_shape else [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
+
+    def make_env():
+        return BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=GRID, groups=groups, device=dev, seed=SEED, env_id_base=env_id_base)
+
+    elapsed, gpu_ms = measure_env(args, make_env(), args.launch, K, W, dist, dev, reduce_dev, rank)
+    alt = {}
+    if not args.no_alt and world == 1:                 # secondary: the other launch forms on the same box, same K / W
+        for other in ("eager", "graph", "many"):
+            if other != args.launch:
+                el, gm = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
+                alt[other] = {"value": E * K / el, "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
+                              "us_per_step_gpu": gm * 1e3 / K}
+    a2c = None
+    if not args.no_a2c and baseline_shape:
+        try:
+            a2c = measure_a2c(args, dist, dev, reduce_dev, rank, world, A2C_ENVS, args.a2c_rollouts)
+        except Exception as ex:                        # the headline line must survive a failure of the appended measurement
+            a2c = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     if rank == 0:
-        per_launch_s = gpu_ms * 1e-3 / K  # average launch-to-launch time of the step kernel (HIP events)
+        per_step_s = gpu_ms * 1e-3 / K   # average per-step device time (HIP events on the launch stream around the timed region)
         b_step = algorithmic_bytes_per_env_step(n_ue, n_bs, len(groups))
-        achieved = b_step * E / per_launch_s / 1e9
+        achieved = b_step * E / per_step_s / 1e9
+        cnt = committed_counters(E) if (baseline_shape and args.launch != "many") else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "traffic_source": None,
+                "kernel": (STEP_KERNEL if args.launch != "many" else STEP_KERNEL.replace("false>", "true>")) if baseline_shape
+                else "env kernel of this shape (secondary measurement)",
+                "algorithmic_bytes_per_launch": b_step * E * (1 if args.launch != "many" else min(CHUNK, K)),
+                "avg_launch_us": per_step_s * 1e6 * (1 if args.launch != "many" else min(CHUNK, K)),
+                "avg_step_us": per_step_s * 1e6,
+                "transcendental_evals_per_step": transcendental_evals_per_env_step(n_ue, n_bs) * E,
+                "transcendental_evals_per_s": transcendental_evals_per_env_step(n_ue, n_bs) * E / per_step_s}
+        if cnt is not None:
+            # FETCH_SIZE on gfx950 counts 64 B per 128-B request for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM):
+            # every state load of this kernel is such a dwordx4 record load, hence the x2; WRITE_SIZE is exact.
+            fetch = 2 * int(cnt["fetch_size_bytes_raw"])
+            roof["traffic"] = fetch + int(cnt["write_size_bytes_raw"])
+            roof["traffic_over_algorithmic"] = roof["traffic"] / float(b_step * E)
+            roof["traffic_source"] = ("profiles/traffic_current.json: committed rocprofv3 PMC passes of this kernel (FETCH_SIZE x2 "
+                                      "gfx950 correction + WRITE_SIZE), NOT measured by this run")
+            if cnt.get("valu_insts_per_wave") and cnt.get("waves_per_launch"):
+                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                roof["valu_issue_frac"] = (cnt["valu_insts_per_wave"] * cnt["waves_per_launch"]) / (n_simd * SIMD_ISSUE_HZ * per_step_s)
+                roof["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed profile) / (%d SIMDs x 0.6 G wave-instr/s) / measured "
+                                           "step time: the roof that actually bounds this float64-ALU kernel" % n_simd)
         line = {
             "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
-            "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "unit": "env-steps/s", "n_gpus": n_ranks, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=100, HIP step(), "
-                                   "compact outputs, on-device Philox, one launch per step" % (
-                                       E, n_bs, n_ue, ",".join(str(g) for g in groups)),
+            "dtype": "f64", "data": "synthetic", "launch": args.launch,
+            "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=100, HIP step(), compact outputs, "
+                                   "on-device Philox, %s" % (E, n_bs, n_ue, ",".join(str(g) for g in groups),
+                                                             {"graph": "one kernel per step, hipGraph replay of <=100-step chunks",
+                                                              "eager": "one kernel launch per step from Python",
+                                                              "many": "uavenv_step_many, <=100 steps per launch"}[args.launch]),
                        "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": GRID, "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(E) if baseline_shape else None,
-                         "kernel": STEP_KERNEL if baseline_shape else "env kernel of this shape (secondary measurement)", "algorithmic_bytes_per_launch": b_step * E,
-                         "avg_launch_us": per_launch_s * 1e6,
-                         "transcendental_evals_per_launch": transcendental_evals_per_env_step(n_ue, n_bs) * E,
-                         "transcendental_evals_per_s": transcendental_evals_per_env_step(n_ue, n_bs) * E / per_launch_s},
+            "roofline": roof,
         }
+        if alt:
+            line["other_launch_forms"] = alt
+        if a2c is not None:
+            line["a2c"] = a2c
         if world == 1 and not args.no_cpu_baseline and baseline_shape:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -42,7 +42,7 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
-ABI_VERSION = 2   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
+ABI_VERSION = 3   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
 STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
@@ -51,7 +51,7 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_trace",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10")
 
@@ -90,6 +90,7 @@ def load():
     lib.uavenv_reset.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_reset_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_obs_dense.argtypes = [_P, _P, _P]
     lib.uavenv_obs_dense_update.argtypes = [_P, _P, _P]

@@ -271,11 +271,15 @@ class A2CRunner:
             ((a_loss + c_loss) * w).backward()                # disjoint parameter sets: same grads as two backward()s
             a_tot += float(a_loss.detach()) * w
             c_tot += float(c_loss.detach()) * w
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         n_red = allreduce_mean_grads(self.net.actor_params() + self.net.critic_params())
+        ev1.record()
         self.opt_a.step()
         self.opt_c.step()
         self.stats = {"a_loss": a_tot, "c_loss": c_tot, "mean_reward": float(rew_buf.mean()), "grad_elems": n_red,
                       "running_r": self.running_r}
+        self.stats["allreduce_ms"] = ev0.elapsed_time(ev1)     # (float(...) above has synchronised)
         return self.stats
 
     def train_rollout(self):

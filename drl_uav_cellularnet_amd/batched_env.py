@@ -196,6 +196,51 @@ class BatchedMobiEnv:
         return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
                                                              "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
 
+    def capture_steps(self, actions):
+        """A hipGraph of len(actions) step() launches (one kernel node per step, step t reading ``actions[t]``): ``g.replay()``
+        then costs one graph launch instead of T host calls -- the per-step host cost (ctypes call + hipLaunchKernel, ~8 us
+        from Python, tools/host_floor.py) is what bounds a 4096-env batch, not the kernel.  Outputs go to ``self.out`` as
+        with step(), so after a replay they hold the last step's results.  ``actions`` int64 [T, N] on this device; the graph
+        reads that tensor at replay time (refill it in place to feed new actions).  Capturing executes nothing."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()
+                and a.dim() == 2 and a.shape[1] == self.n_envs):
+            raise ValueError("actions must be a contiguous int64 [T, n_envs] tensor on the env's device")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            stream = self._stream()                      # the capturing stream
+            for t in range(int(a.shape[0])):
+                _capi.check(self._lib.uavenv_step(self._h, a[t].data_ptr(), None, self._out_ref, stream))
+        g._uavenv_keep = (a, self)                       # the graph holds raw pointers into both
+        return g
+
+    def step_many(self, actions, out=None, refresh_out=True):
+        """T consecutive step() calls in ONE launch (uavenv_step_many) for actions that do not depend on the observations in
+        between: ``actions`` int64 [T, N] on this device.  Returns a dict of [T, ...] tensors (block t = what step t returned;
+        same names and dtypes as ``self.out``); ``self.out`` is then refreshed with the last step's block (``refresh_out``), so
+        observation() and the step()/reset() API continue from there.  Bit-identical to T step() calls.  ``out``: a dict previously returned for
+        the same T, to be overwritten instead of allocating."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int64).contiguous()
+            self._act_keep = a
+        if a.dim() != 2 or a.shape[1] != self.n_envs:
+            raise ValueError("actions must be [T, n_envs]")
+        T = int(a.shape[0])
+        if out is None:
+            out = {k: torch.empty((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) for k, v in self.out.items()}
+        elif set(out) != set(self.out) or any(out[k].shape != (T,) + tuple(v.shape) or not out[k].is_contiguous()
+                                               for k, v in self.out.items()):
+            raise ValueError("out must be a dict returned by step_many for the same number of steps")
+        st = _capi.UavEnvOut()
+        for k, v in out.items():
+            setattr(st, k + "_dev", v.data_ptr())
+        _capi.check(self._lib.uavenv_step_many(self._h, a.data_ptr(), T, C.byref(st), self._stream()))
+        if T > 0 and refresh_out:                        # (refresh_out=False: self.out goes stale until the next step()/reset())
+            for k, v in self.out.items():
+                v.copy_(out[k][T - 1])
+        return out
+
     def step_trace(self, actions, ue_xy, fading=None):
         """MobiEnvironment.step_test with mobility_model == 'read_trace' (mobile_env.py:196-233)."""
         a = self._actions(actions)

@@ -297,7 +297,7 @@ static bool call_is_fast(const KParams &p) {
            o.bs_xy && o.serving && o.cur_sinr && o.step_n && !o.cur_sinr_f64 && !o.mean_sinr_f64 && !o.reward_f64;
 }
 
-template <int MODE>
+template <int MODE, bool MANY = false>
 static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
     const long long waves = (p.N + p.epw - 1) / p.epw;
@@ -328,15 +328,15 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
-        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true>), dim3(grid), blk, 0, s, PK_ARGS);     \
-        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false>), dim3(grid), blk, 0, s, PK_ARGS); \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false>), dim3(grid), blk, 0, s, PK_ARGS);       \
+        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY>), dim3(grid), blk, 0, s, PK_ARGS);     \
+        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY>), dim3(grid), blk, 0, s, PK_ARGS); \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY>), dim3(grid), blk, 0, s, PK_ARGS);       \
     } while (0)
 #define UAVENV_LAUNCH(BT_)                                                                                       \
     do {                                                                                                         \
         if (h->packed) {                                                                                         \
             if (h->plc) UAVENV_LAUNCH_PK(BT_, true); else UAVENV_LAUNCH_PK(BT_, false);                          \
-        } else {                                                                                                 \
+        } else if (!MANY) {                                                                                      \
             if (h->plc) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true>), dim3(grid), blk, 0, s, p);      \
             else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false>), dim3(grid), blk, 0, s, p);            \
         }                                                                                                        \
@@ -398,6 +398,46 @@ extern "C" int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnv
     fill_call(p, inj, out);
     p.actions = (const long long *)actions_dev; p.n_ticks = 1;
     return launch_env<MODE_STEP>(h, p, (hipStream_t)stream);
+}
+
+// Output block of step t in the [T][...] arrays of a multi-step call (uavenv_step_many); null members stay null.
+static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long long U, long long B) {
+    UavEnvOut r = o;
+    if (r.reward_dev) r.reward_dev += t * N;
+    if (r.done_dev) r.done_dev += t * N;
+    if (r.mean_sinr_dev) r.mean_sinr_dev += t * N;
+    if (r.n_out_dev) r.n_out_dev += t * N;
+    if (r.ue_xy_dev) r.ue_xy_dev += t * N * U * 2;
+    if (r.bs_xy_dev) r.bs_xy_dev += t * N * B * 2;
+    if (r.serving_dev) r.serving_dev += t * N * U;
+    if (r.cur_sinr_dev) r.cur_sinr_dev += t * N * U;
+    if (r.step_n_dev) r.step_n_dev += t * N;
+    if (r.cur_sinr_f64_dev) r.cur_sinr_f64_dev += t * N * U;
+    if (r.mean_sinr_f64_dev) r.mean_sinr_f64_dev += t * N;
+    if (r.reward_f64_dev) r.reward_f64_dev += t * N;
+    return r;
+}
+
+extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream) {
+    if (!h || !actions_dev || n_steps < 0) return fail(UAVENV_E_INVALID, "step_many: null handle / actions or negative n_steps");
+    if (n_steps == 0) return UAVENV_OK;
+    DeviceGuard guard(h->device);
+    if (h->packed) {   // one launch: state stays in registers across the steps (env_kernel_packed<..., MANY = true>)
+        KParams p = h->kp;
+        fill_call(p, nullptr, out);
+        p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
+        return launch_env<MODE_STEP, true>(h, p, (hipStream_t)stream);
+    }
+    // multi-pass handles (n_ue > 64): one single-step launch per step on the same stream, each writing its own output block
+    for (int t = 0; t < n_steps; ++t) {
+        KParams p = h->kp;
+        UavEnvOut blk;
+        if (out) blk = out_block(*out, t, h->N, h->cfg.n_ue, h->cfg.n_bs);
+        fill_call(p, nullptr, out ? &blk : nullptr);
+        p.actions = (const long long *)actions_dev + (long long)t * h->N; p.n_ticks = 1;
+        if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
+    }
+    return UAVENV_OK;
 }
 
 extern "C" int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,

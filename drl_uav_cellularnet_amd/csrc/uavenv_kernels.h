@@ -515,22 +515,24 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 // Per-env scalars and outputs after a step / reset: reward (mobile_env.py:163-189), done (:186-187).
 // `rec` is the env's record as loaded at kernel entry: fields a mode does not own keep their value (the aggregation counters in
 // the trace modes, depth and step count during warm-up), and the whole record goes back with one 32-byte store.
-template <int MODE, bool FAST>
-__device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st, uint32_t e, EnvRec rec, uint32_t tick, int agg, int deagg,
-                                           int depth, int step_n, double sum_cur, int n_outage) {
+// `o`: where this step's outputs go (p.out, or the current step's block of a multi-step launch).  REC = false: outputs only
+// (steps 0 .. T-2 of a multi-step launch; the record is stored once, after the last step).
+template <int MODE, bool FAST, bool REC = true>
+__device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, const StatePtrs &st, uint32_t e, EnvRec rec, uint32_t tick,
+                                           int agg, int deagg, int depth, int step_n, double sum_cur, int n_outage) {
     rec.tick = tick;
     if (has_mobility(MODE)) { rec.agg = agg; rec.deagg = deagg; }
     if (is_reset(MODE)) {
         rec.fifo_depth = 1;                                    // bestBS_buf = [current_BS] (channel.py:115)
         rec.step_n = 0;                                        // mobile_env.py:146
         const double mean = sum_cur * p.inv_U;
-        if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, 0);
-        if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, 0.f);
-        if (UAV_OUT64(p.out.reward_f64)) stx(p.out.reward_f64, e, 0.0);
-        if (UAV_OUT(p.out.done)) stx(p.out.done, e, 0);
-        if (UAV_OUT(p.out.n_out)) stx(p.out.n_out, e, 0);
-        if (UAV_OUT(p.out.mean_sinr)) stx(p.out.mean_sinr, e, (float)mean);
-        if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
+        if (UAV_OUT(o.step_n)) stx(o.step_n, e, 0);
+        if (UAV_OUT(o.reward)) stx(o.reward, e, 0.f);
+        if (UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, 0.0);
+        if (UAV_OUT(o.done)) stx(o.done, e, 0);
+        if (UAV_OUT(o.n_out)) stx(o.n_out, e, 0);
+        if (UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
+        if (UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
     }
     if (is_step(MODE)) {
         rec.fifo_depth = depth < 3 ? depth + 1 : depth;
@@ -541,15 +543,34 @@ __device__ __forceinline__ void env_finish(const KParams &p, const StatePtrs &st
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
         rec.step_n = step_n;
-        if (UAV_OUT(p.out.step_n)) stx(p.out.step_n, e, step_n);
-        if (UAV_OUT(p.out.done)) stx(p.out.done, e, (uint8_t)(step_n >= p.max_step));
-        if (UAV_OUT(p.out.reward)) stx(p.out.reward, e, (float)reward);
-        if (UAV_OUT64(p.out.reward_f64)) stx(p.out.reward_f64, e, reward);
-        if (UAV_OUT(p.out.mean_sinr)) stx(p.out.mean_sinr, e, (float)mean);
-        if (UAV_OUT64(p.out.mean_sinr_f64)) stx(p.out.mean_sinr_f64, e, mean);
-        if (UAV_OUT(p.out.n_out)) stx(p.out.n_out, e, n_outage);
+        if (UAV_OUT(o.step_n)) stx(o.step_n, e, step_n);
+        if (UAV_OUT(o.done)) stx(o.done, e, (uint8_t)(step_n >= p.max_step));
+        if (UAV_OUT(o.reward)) stx(o.reward, e, (float)reward);
+        if (UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, reward);
+        if (UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
+        if (UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
+        if (UAV_OUT(o.n_out)) stx(o.n_out, e, n_outage);
     }
-    stx(st.env, e, rec);
+    if (REC) stx(st.env, e, rec);
+}
+
+// Multi-step launches (uavenv_step_many): every output array holds one block per step, [T][...]; the pointers move on by one
+// block after each step (uniform 64-bit adds on the scalar unit).  A null (skipped) output stays null.
+template <bool FAST>
+__device__ __forceinline__ void out_next_step(OutPtrs &o, long long N, int U, int B) {
+    const long long nu = N * U, nb2 = N * B * 2;
+    if (UAV_OUT(o.reward)) o.reward += N;
+    if (UAV_OUT(o.done)) o.done += N;
+    if (UAV_OUT(o.mean_sinr)) o.mean_sinr += N;
+    if (UAV_OUT(o.n_out)) o.n_out += N;
+    if (UAV_OUT(o.ue_xy)) o.ue_xy += 2 * nu;
+    if (UAV_OUT(o.bs_xy)) o.bs_xy += nb2;
+    if (UAV_OUT(o.serving)) o.serving += nu;
+    if (UAV_OUT(o.cur_sinr)) o.cur_sinr += nu;
+    if (UAV_OUT(o.step_n)) o.step_n += N;
+    if (UAV_OUT64(o.cur_sinr_f64)) o.cur_sinr_f64 += nu;
+    if (UAV_OUT64(o.mean_sinr_f64)) o.mean_sinr_f64 += N;
+    if (UAV_OUT64(o.reward_f64)) o.reward_f64 += N;
 }
 
 // ================================================================================================
@@ -605,10 +626,16 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // Host guarantees U >= max(B, Gr) (owner lanes live inside the slot) and EPW*U <= 64.
 // BT: compile-time bound on B.  PLC: pl_b == 30 (channel.py:47) => d^-3 by sqrt.
 // ================================================================================================
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN>
+// MANY (MODE_STEP only): p.n_ticks whole steps in ONE launch -- uavenv_step_many.  State is loaded once, lives in registers
+// across the steps and is stored once; step t reads actions[t][N] (the next step's action is prefetched while this step
+// computes) and writes block t of every output array.  Exactly the arithmetic of p.n_ticks single-step launches, so results
+// are bit-identical (tests/test_step_many_gpu.py); what disappears is the per-step launch, kernarg fetch, state load round
+// trip and state store, i.e. the fixed ~5.8 us a 4096-env launch spends outside its arithmetic.
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
                                                                               int Gr, int B_rt, int lane_magic, const KParams p) {
+    static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
     // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
     // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
@@ -629,7 +656,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     if (__ballot(live) == 0ull) return;
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
     const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
-    const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
+    const int n_ticks = (MODE == MODE_WARMUP || MANY) ? p.n_ticks : 1;   // iterations of the tick / step loop below
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
     const long long iu = e * U + (live ? u : 0);
@@ -665,8 +692,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     const EnvRec erec = ldx(st.env, e32);                      // tick, phase counters, FIFO depth, step count: one record
     uint32_t tick = erec.tick;
     int agg = erec.agg, deagg = erec.deagg;
-    const int depth = erec.fifo_depth;
-    const int step_n = erec.step_n;
+    int depth = erec.fifo_depth;      // (advances only between the steps of a multi-step launch)
+    int step_n = erec.step_n;
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
         const GrpRec g = ldx(st.grp, ig32);
@@ -706,43 +733,57 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     int n_outage = (int)(prev_out & 1ull) + serving + r0 + r1 + r2 + depth;
     unsigned long long ob = prev_out;
     tick += 1u;
-    (void)bs_row; (void)slot_mask; (void)n_ticks; (void)MAXC; (void)hu_inj; (void)C; (void)H;
+    OutPtrs om = p.out;
+    (void)bs_row; (void)slot_mask; (void)n_ticks; (void)MAXC; (void)hu_inj; (void)C; (void)H; (void)om;
 #else
-    // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
-    if (MODE != MODE_WARMUP) {
-        if (REG_MOVE) {
-            if (is_step(MODE)) bs_move_serial<BT, FAST>(p, (unsigned)act, bsx, bsy);
-#pragma unroll
-            for (int b = 0; b < BT; ++b)
-                if (ul == b) { bx = bsx[b]; by = bsy[b]; }             // the cell this lane writes back
-        } else {
-            // cooperative form for B > 8: one UAV per lane, sequential rounds, UAV cells staged in LDS
-            if (is_step(MODE)) {
-                int dig = 0;
-                if (bown) dig = action_digit(p, act, apw);
-                for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
-                    const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
-                    int nx, ny;
-                    uav_propose(p, xi, yi, di, nx, ny);
-                    // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
-                    const int dx = xi - bx, dy = yi - by;
-                    const bool near = bown && (ul != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
-                    const bool collision = (__ballot(near) & slot_mask) != 0ull;
-                    if (!collision && bown && ul == i) { bx = nx; by = ny; }
-                }
-            }
-            if (bown) { bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by; }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int b = 0; b < BT; ++b)
-                if (b < B) { bsx[b] = bs_row[2 * b]; bsy[b] = bs_row[2 * b + 1]; }
-        }
-    }
-
-    UAV_STAMP(ts3);                                   // UAV move done
-    // ---- mobility: n_ticks x next(self.mm); walker and group state stay in registers across ticks ----
+    // One loop body serves all launch kinds: warm-up = n_ticks mobility ticks (no UAV move, no channel update); reset / step =
+    // exactly one iteration (compile-time trip count, the loop folds away); multi-step (MANY) = n_ticks whole steps, each
+    // storing its outputs, with walker / group / UAV state carried in registers.
     U4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};   // this walker's Philox calls 0 / 1 of the last tick (heading + fading)
+    double sum_cur = 0.0, cur = 0.0;
+    int n_outage = 0;
+    unsigned long long ob = 0ull;
+    OutPtrs om = p.out;                                // MANY: the current step's output blocks (dead code otherwise)
     for (int it = 0; it < n_ticks; ++it) {
+        long long act_next = 0;
+        if (MANY) {                                    // prefetch the next step's action: its round trip hides behind this step
+            const long long *nxt = actions + (long long)((it + 1 < n_ticks) ? it + 1 : it) * N;
+            if (REG_MOVE || bown) act_next = ldx(nxt, e32);
+        }
+        // ---- UAV move: Decimal_to_Base_N + BS_move (ue_mobility.py:191-271,310-336) ---------------
+        if (MODE != MODE_WARMUP) {
+            if (REG_MOVE) {
+                if (is_step(MODE)) bs_move_serial<BT, FAST>(p, (unsigned)act, bsx, bsy);
+#pragma unroll
+                for (int b = 0; b < BT; ++b)
+                    if (ul == b) { bx = bsx[b]; by = bsy[b]; }             // the cell this lane writes back
+            } else {
+                // cooperative form for B > 8: one UAV per lane, sequential rounds, UAV cells staged in LDS
+                if (is_step(MODE)) {
+                    int dig = 0;
+                    if (bown) dig = action_digit(p, act, apw);
+                    for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
+                        const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
+                        int nx, ny;
+                        uav_propose(p, xi, yi, di, nx, ny);
+                        // collision on the PRE-move cell of i (:256-263); integer form of norm <= min_dist
+                        const int dx = xi - bx, dy = yi - by;
+                        const bool near = bown && (ul != i) && (dx * dx + dy * dy <= p.min_bs_dist2);
+                        const bool collision = (__ballot(near) & slot_mask) != 0ull;
+                        if (!collision && bown && ul == i) { bx = nx; by = ny; }
+                    }
+                }
+                if (MANY) __builtin_amdgcn_wave_barrier();             // the previous step's reads of bs_row are done
+                if (bown) { bs_row[2 * ul] = bx; bs_row[2 * ul + 1] = by; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int b = 0; b < BT; ++b)
+                    if (b < B) { bsx[b] = bs_row[2 * b]; bsy[b] = bs_row[2 * b + 1]; }
+            }
+        }
+
+        if (!MANY) UAV_STAMP(ts3);                        // UAV move done
+        // ---- mobility: next(self.mm); walker and group state stay in registers across ticks ----
         if (has_mobility(MODE)) {
             const bool aggregating = agg != 0;
             if (gown) {                                          // ue_mobility.py:458-459
@@ -776,34 +817,51 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }                        // :486-487
         }
         tick += 1u;
-    }
-    if (has_mobility(MODE)) { ix = (int)x; iy = (int)y; }                                // .astype(int), mobile_env.py:154-155
+        if (MODE == MODE_WARMUP) continue;                // warm-up: mobility only
+        if (has_mobility(MODE)) { ix = (int)x; iy = (int)y; }                            // .astype(int), mobile_env.py:154-155
 
-    UAV_STAMP(ts4);                                   // mobility done
-    // ---- channel update (one per reset / step; Philox time = the tick just executed) ------------------
-    double sum_cur = 0.0, cur = 0.0;
-    int n_outage = 0;
-    unsigned long long ob = 0ull;
-    if (MODE != MODE_WARMUP) {
-        double pg[BT];
-        rx_power<BT, PLC, FAST, FAST && has_mobility(MODE)>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, q0, q1, pg);
-        double best_pg;
-        const int best = argmax_pg<BT, FAST>(p, pg, best_pg);
-        const double bestS = sinr_db_px<BT, FAST>(p, H, C, pg, best, best_pg);
-        if (is_reset(MODE)) {
-            // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
-            cur = bestS;
-            serving = best;
-            r0 = best;                                                                   // bestBS_buf = [current_BS]
-        } else {
-            // UpdateDroneNet, DL part (channel.py:141-174)
-            cur = sinr_db<BT, FAST>(p, H, C, pg, serving);       // serving UAV BEFORE any handover (:145-146)
-            fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
+        if (!MANY) UAV_STAMP(ts4);                        // mobility done
+        // ---- channel update (one per reset / step; Philox time = the tick just executed) ------------------
+        {
+            double pg[BT];
+            rx_power<BT, PLC, FAST, FAST && has_mobility(MODE)>(p, H, C, e, tick - 1u, u, live, iu, ix, iy, bsx, bsy, q0, q1, pg);
+            double best_pg;
+            const int best = argmax_pg<BT, FAST>(p, pg, best_pg);
+            const double bestS = sinr_db_px<BT, FAST>(p, H, C, pg, best, best_pg);
+            if (is_reset(MODE)) {
+                // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
+                cur = bestS;
+                serving = best;
+                r0 = best;                                                                   // bestBS_buf = [current_BS]
+            } else {
+                // UpdateDroneNet, DL part (channel.py:141-174)
+                cur = sinr_db<BT, FAST>(p, H, C, pg, serving);       // serving UAV BEFORE any handover (:145-146)
+                fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
+            }
+            ob = (__ballot(live && (cur <= H.out_thr)) & slot_mask) >> base;               // :116 / :170
+            if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
+            sum_cur = slot_sum(live ? cur : 0.0, ul, U);
         }
-        ob = (__ballot(live && (cur <= H.out_thr)) & slot_mask) >> base;               // :116 / :170
-        if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
-        sum_cur = slot_sum(live ? cur : 0.0, ul, U);
+        if (MANY) {
+            // ---- this step's outputs (block `it` of every output array), then the hand-over to the next step ------------
+            if (live) {
+                if (UAV_OUT(om.ue_xy)) { stx(om.ue_xy, 2u * iu32, (int16_t)ix); stx(om.ue_xy, 2u * iu32 + 1u, (int16_t)iy); }
+                if (UAV_OUT(om.serving)) stx(om.serving, iu32, (int8_t)serving);
+                if (UAV_OUT(om.cur_sinr)) stx(om.cur_sinr, iu32, (float)cur);
+                if (UAV_OUT64(om.cur_sinr_f64)) stx(om.cur_sinr_f64, iu32, cur);
+            }
+            if (bown) { if (UAV_OUT(om.bs_xy)) { stx(om.bs_xy, 2u * ib32, bx); stx(om.bs_xy, 2u * ib32 + 1u, by); } }
+            if (it + 1 < n_ticks) {
+                if (head) env_finish<MODE, FAST, false>(p, om, st, e32, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+                out_next_step<FAST>(om, N, U, B);
+                prev_out = ob;                                    // channel.py:173  self.ue_out = new_out
+                depth = depth < 3 ? depth + 1 : depth;            // bestBS_buf grows to hoBufDepth, then shifts (:148-153)
+                step_n += 1;                                      // mobile_env.py:181
+                act = act_next;
+            }
+        }
     }
+    if (MODE == MODE_WARMUP) { ix = (int)x; iy = (int)y; }                               // cells after the last warm-up tick
 #endif  // UAVENV_SKELETON
     UAV_STAMP(ts5);                                   // channel update done
 
@@ -813,7 +871,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         if (has_mobility(MODE)) stx(st.ue_pos, iw, UePos{x, y});
         // warm-up leaves serving and the FIFO rows as loaded; a reset overwrites serving and row 0 only (depth becomes 1)
         stx(st.ue_aux, iw, UeAux{hu, (int16_t)ix, (int16_t)iy, (int8_t)serving, (int8_t)r0, (int8_t)r1, (int8_t)r2});
-        if (MODE != MODE_WARMUP) {
+        if (MODE != MODE_WARMUP && !MANY) {
             if (UAV_OUT(p.out.ue_xy)) { stx(p.out.ue_xy, 2u * iw, (int16_t)ix); stx(p.out.ue_xy, 2u * iw + 1u, (int16_t)iy); }
             if (UAV_OUT(p.out.serving)) stx(p.out.serving, iw, (int8_t)serving);
             if (UAV_OUT(p.out.cur_sinr)) stx(p.out.cur_sinr, iw, (float)cur);
@@ -827,12 +885,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     if (bown) {
         const uint32_t bw = block_local<!PIN>(ib32);
         stx(st.bs_xy, 2u * bw, bx); stx(st.bs_xy, 2u * bw + 1u, by);
-        if (UAV_OUT(p.out.bs_xy)) { stx(p.out.bs_xy, 2u * bw, bx); stx(p.out.bs_xy, 2u * bw + 1u, by); }
+        if (!MANY) { if (UAV_OUT(p.out.bs_xy)) { stx(p.out.bs_xy, 2u * bw, bx); stx(p.out.bs_xy, 2u * bw + 1u, by); } }
     }
     if (head) {
         const uint32_t ew = block_local<!PIN>(e32);
         if (MODE != MODE_WARMUP) stx(st.out_bits, ew, ob);                                // :116 / :173
-        env_finish<MODE, FAST>(p, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        // (MANY: outputs of the LAST step + the record; depth / step_n are the values that step started from)
+        env_finish<MODE, FAST>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -1010,7 +1069,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
         }
         tick += 1u;
     }
-    if (lane == 0) env_finish<MODE, FAST>(p, st, (uint32_t)e, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+    if (lane == 0) env_finish<MODE, FAST>(p, p.out, st, (uint32_t)e, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
 // ================================================================================================

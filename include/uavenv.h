@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 2   /* 2: state blob = arrays of records (UavEnvStateLayout); entry points unchanged */
+#define UAVENV_ABI_VERSION 3   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -124,6 +124,14 @@ int uavenv_reset(uavenv_t *h, const uint8_t *mask_dev, const UavEnvInject *inj, 
 /* MobiEnvironment.step (mobile_env.py:150-194): one fused kernel launch for all N envs. */
 int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj, const UavEnvOut *out,
                 void *stream);
+/* n_steps consecutive MobiEnvironment.step calls (mobile_env.py:150-194) in ONE launch, for callers whose actions do not depend on
+ * the observations in between (a random policy, main.py's warm-up exploration; an action tape): actions_dev is [n_steps, N]
+ * (step t uses row t) and every non-NULL member of `out` points to n_steps consecutive blocks of the single-step shape, e.g.
+ * reward_dev [n_steps, N], ue_xy_dev [n_steps, N, U, 2]; block t holds what step t returned.  Bit-identical to n_steps calls of
+ * uavenv_step with on-device randomness (no draws can be injected); no auto-reset, like the reference: envs that pass MAXSTEP
+ * keep stepping with done = 1.  n_ue <= 64: walker / group / UAV state stays in registers across the steps (no per-step launch,
+ * state load or state store); n_ue > 64: n_steps single-step launches on `stream`. */
+int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream);
 /* MobiEnvironment.step_test in read_trace mode (mobile_env.py:196-233): UE cells come from ue_xy_in_dev [N,U,2]. */
 int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
                       const UavEnvInject *inj, const UavEnvOut *out, void *stream);

@@ -1,0 +1,109 @@
+"""Oracle parity AT the benchmark's real grid sizes ("parity on first 64 steps" at N = 4096; VERDICT r1
+"What's missing" #2).  The exact launch shapes bench.py times -- 4096 envs (the PINNED FAST kernel, 1366 wavefronts with a ragged
+last one), 8192 and 65536 envs (the unpinned FAST kernel) -- run 64 steps on the device; the oracle replays 64-env WINDOWS of the
+big batch (OracleEnv(..., 64, env_id_base=k) owns the same Philox streams as envs k..k+63 of one big batch) at the start, in the
+middle and over the ragged last wavefront.  Integers exact, float32 within 1e-5 relative (north_star).
+Also: the same comparison through uavenv_step_many and through a replayed hipGraph at 4096 envs, and BASELINE config 3 at its
+full size (8192 envs x 50-step rollout + one update)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STEPS, WIN = 64, 64
+INT_KEYS = ("ue_xy", "bs_xy", "serving", "n_out", "step_n", "done")
+F32_KEYS = ("cur_sinr", "mean_sinr", "reward")
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _windows(n):
+    last = n - WIN                       # covers the last (ragged: 3 envs per wavefront, n % 3 != 0) wavefront
+    return sorted({0, ((n // 2) // 3) * 3 + 1, last})     # the middle window starts inside a wavefront (slot 1)
+
+
+def _oracles(n):
+    from oracle import oracle as O
+
+    cfg = O.make_config(4, 20, 100, groups=[5, 5, 5, 5])
+    out = []
+    for k in _windows(n):
+        o = O.OracleEnv(cfg, WIN, seed=0x5EED, env_id_base=k)
+        first = o.construct()
+        out.append((k, o, first))
+    return out
+
+
+def _compare(got, want, k, what):
+    for key in INT_KEYS:
+        assert np.array_equal(got[key][k:k + WIN].cpu().numpy(), want[key]), "%s: %s differs, window %d" % (what, key, k)
+    for key in F32_KEYS:
+        np.testing.assert_allclose(got[key][k:k + WIN].cpu().numpy(), want[key], rtol=1e-5, atol=0,
+                                   err_msg="%s: %s, window %d" % (what, key, k))
+
+
+@pytest.mark.parametrize("n_envs", [4096, 8192, 65536])
+def test_bench_sized_batches_match_the_oracle_on_windows(n_envs):
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    env = BatchedMobiEnv(n_envs, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], seed=0x5EED)
+    orcs = _oracles(n_envs)
+    for k, _, first in orcs:
+        _compare(env.out, first, k, "constructor")
+    gen = torch.Generator().manual_seed(1234)
+    for t in range(STEPS):
+        a = torch.randint(0, 625, (n_envs,), generator=gen, dtype=torch.int64)
+        env.step(a.to(env.device))
+        a_np = a.numpy()
+        for k, o, _ in orcs:
+            _compare(env.out, o.step(a_np[k:k + WIN]), k, "step %d" % t)
+
+
+def test_step_many_and_graph_at_4096_envs_match_the_oracle_on_windows():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    n = 4096
+    env_m = BatchedMobiEnv(n, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], seed=0x5EED)
+    env_g = env_m.clone()
+    orcs = _oracles(n)
+    gen = torch.Generator().manual_seed(99)
+    tape = torch.randint(0, 625, (STEPS, n), generator=gen, dtype=torch.int64)
+    dev_tape = tape.to(env_m.device)
+    many = env_m.step_many(dev_tape)
+    g = env_g.capture_steps(dev_tape)
+    g.replay()
+    torch.cuda.synchronize()
+    a_np = tape.numpy()
+    for t in range(STEPS):
+        for k, o, _ in orcs:
+            want = o.step(a_np[t, k:k + WIN])
+            _compare({key: many[key][t] for key in INT_KEYS + F32_KEYS}, want, k, "step_many step %d" % t)
+            if t == STEPS - 1:
+                _compare(env_g.out, want, k, "graph replay, last step")
+    assert np.array_equal(env_m.get_state(), env_g.get_state())
+
+
+def test_a2c_config3_at_full_size():
+    """BASELINE configs[2]: 8192 envs + MLP actor-critic, one 50-step rollout and one update at full size."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner
+
+    env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+    runner = A2CRunner(env, rollout=50)
+    w0 = runner.net.c_w2.detach().clone()
+    for it in range(2):
+        st = runner.train_rollout()
+        assert np.isfinite(st["a_loss"]) and np.isfinite(st["c_loss"]) and np.isfinite(st["mean_reward"])
+        assert st["grad_elems"] == 20206626
+        assert int(env.out["step_n"].min()) == int(env.out["step_n"].max()) == 50 * (it + 1)
+    assert not torch.equal(w0, runner.net.c_w2.detach())
+    assert all(bool(torch.isfinite(p).all()) for p in runner.net.parameters())

@@ -1,0 +1,135 @@
+"""uavenv_step_many (T steps in one launch, state carried in registers) and hipGraph replay of T step() launches against
+T plain uavenv_step calls from the same state: every output of every step and the final state blob BIT-IDENTICAL.
+(uavenv_step itself is checked against the reference fixtures and the oracle in test_hip_parity.py; this file adds the
+oracle at a few points so that the multi-step path is also pinned directly.)  Reference: mobile_env.py:150-194 called T times."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _env(n, n_bs, n_ue, **kw):
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    groups = [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
+    return BatchedMobiEnv(n, nBS=n_bs, nUE=n_ue, grid_n=kw.pop("grid_n", 100), groups=groups, seed=kw.pop("seed", 77), **kw)
+
+
+def _actions(torch, env, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    hi = min(env.action_space_dim, 2 ** 62)
+    return torch.randint(0, hi, (T, env.n_envs), generator=g, dtype=torch.int64).to(env.device)
+
+
+# (n_envs, n_bs, n_ue, T): packed FAST (3 envs / wavefront, ragged tail), 1 env / wavefront, B != BT (checked variant),
+# B > 8 (cooperative UAV move through LDS inside the step loop), multi-pass (host loop of single-step launches)
+SHAPES = [(100, 4, 20, 1), (100, 4, 20, 2), (100, 4, 20, 7), (1366 * 3 - 1, 4, 20, 5), (50, 4, 40, 9), (33, 3, 20, 6), (20, 8, 20, 5),
+          (10, 16, 60, 6), (4, 16, 200, 3)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%denv_%dx%d_T%d" % s)
+def test_step_many_is_bit_identical_to_single_steps(shape):
+    torch = _torch()
+    n, n_bs, n_ue, T = shape
+    env = _env(n, n_bs, n_ue, f64_outputs=(n_bs == 3))
+    ref = env.clone()
+    act = _actions(torch, env, T, 5)
+    many = env.step_many(act)
+    for t in range(T):
+        ref.step(act[t])
+        for k, v in ref.out.items():
+            assert torch.equal(many[k][t], v), "%s differs at step %d" % (k, t)
+    for k, v in ref.out.items():
+        assert torch.equal(env.out[k], v), k                       # self.out refreshed with the last block
+    assert np.array_equal(env.get_state(), ref.get_state())
+    # and the API continues from there
+    a = _actions(torch, env, 1, 9)[0]
+    env.step(a); ref.step(a)
+    for k, v in ref.out.items():
+        assert torch.equal(env.out[k], v), k
+
+
+def test_step_many_long_run_crosses_phases_done_and_matches_oracle():
+    """150 steps: FIFO depth 1 -> 3, aggregation phase changes (tick 200 + 100 + 10 ...), group arrivals, and MAXSTEP = 120 reached
+    inside the launch (done stays 1 and step_n keeps counting, as the reference's step() does without a reset)."""
+    torch = _torch()
+    from oracle import oracle as O
+
+    n, T = 192, 150
+    env = _env(n, 4, 20, max_step=120, seed=0x5EED)
+    ref = env.clone()
+    orc = O.OracleEnv(O.make_config(4, 20, 100, groups=[5, 5, 5, 5], max_step=120), n, seed=0x5EED)
+    orc.construct()
+    act = _actions(torch, env, T, 11)
+    out = env.step_many(act[:100])
+    out2 = env.step_many(act[100:])                                # a second call continues from the stored state
+    act_np = act.cpu().numpy()
+    for t in range(T):
+        ref.step(act[t])
+        oo = orc.step(act_np[t])
+        blk = (out, t) if t < 100 else (out2, t - 100)
+        for k, v in ref.out.items():
+            assert torch.equal(blk[0][k][blk[1]], v), "%s differs at step %d" % (k, t)
+        if t % 10 == 0 or t >= 118:
+            for k in ("ue_xy", "bs_xy", "serving", "n_out", "step_n", "done"):
+                assert np.array_equal(blk[0][k][blk[1]].cpu().numpy(), oo[k]), "oracle: %s at step %d" % (k, t)
+            for k in ("cur_sinr", "mean_sinr", "reward"):
+                np.testing.assert_allclose(blk[0][k][blk[1]].cpu().numpy(), oo[k], rtol=1e-5, atol=0)
+    assert int(out2["done"][-1].min()) == 1 and int(out2["step_n"][-1][0]) == T
+    assert int(out["done"][99].max()) == 0
+    assert np.array_equal(env.get_state(), ref.get_state())
+
+
+def test_step_many_skips_null_outputs_and_rejects_bad_arguments():
+    torch = _torch()
+    import ctypes as C
+
+    from drl_uav_cellularnet_amd import UavEnvError, _capi
+
+    env = _env(64, 4, 20)
+    ref = env.clone()
+    act = _actions(torch, env, 4, 3)
+    # only the reward block requested: the checked kernel variant, everything else NULL
+    rew = torch.empty((4, 64), dtype=torch.float32, device=env.device)
+    st = _capi.UavEnvOut()
+    st.reward_dev = rew.data_ptr()
+    _capi.check(env._lib.uavenv_step_many(env._h, act.data_ptr(), 4, C.byref(st), env._stream()))
+    for t in range(4):
+        ref.step(act[t])
+        assert torch.equal(rew[t], ref.out["reward"])
+    assert np.array_equal(env.get_state(), ref.get_state())
+    assert env._lib.uavenv_step_many(env._h, act.data_ptr(), 0, C.byref(st), env._stream()) == 0      # zero steps: a no-op
+    assert env._lib.uavenv_step_many(env._h, act.data_ptr(), -1, C.byref(st), env._stream()) != 0
+    assert env._lib.uavenv_step_many(env._h, None, 2, C.byref(st), env._stream()) != 0
+    with pytest.raises(ValueError):
+        env.step_many(act[:, :10])
+    with pytest.raises((ValueError, UavEnvError)):
+        env.step_many(act, out={"reward": rew})
+
+
+def test_graph_replay_of_steps_is_bit_identical_to_eager():
+    torch = _torch()
+    env = _env(4096, 4, 20)
+    ref = env.clone()
+    T = 12
+    tape = _actions(torch, env, T, 21)
+    g = env.capture_steps(tape)                                    # capture executes nothing
+    assert np.array_equal(env.get_state(), ref.get_state())
+    for rep in range(3):
+        if rep:
+            tape.copy_(_actions(torch, env, T, 21 + rep))          # the graph reads the tape at replay time
+        g.replay()
+        for t in range(T):
+            ref.step(tape[t])
+        torch.cuda.synchronize()
+        for k, v in ref.out.items():
+            assert torch.equal(env.out[k], v), k
+        assert np.array_equal(env.get_state(), ref.get_state())
