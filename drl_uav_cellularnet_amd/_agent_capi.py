@@ -1,9 +1,8 @@
-"""ctypes binding of libuavagent.so (include/uavagent.h) and the autograd wrapper agent.py uses for CUDA tensors.
+"""ctypes binding of libuavagent.so (include/uavagent.h, ABI 2) and the autograd wrapper agent.py uses for CUDA tensors.
 
-The plain PyTorch form, ``F.embedding_bag(idx, W, mode="sum") + b``, stays in agent.py as the reference implementation and the
-CPU path.  Here: forward = the HIP kernel (one launch for the actor and the critic table, which share their indices);
-backward = ATen's own ``_embedding_bag_dense_backward`` -- the routine autograd runs for embedding_bag -- so gradients are
-the reference's by construction.  A CUDA tensor with no library is an error, not a silent PyTorch fallback.
+The plain PyTorch forms stay in agent.py as the reference implementations and the CPU path.  Here: thin launch wrappers (no
+allocation beyond outputs, current torch stream) for the first layer, index construction, action sampling and the pieces of
+the fused update.  A CUDA tensor with no library is an error, not a silent PyTorch fallback.
 """
 import ctypes as C
 import os
@@ -12,9 +11,14 @@ import torch
 
 from . import build as _build
 
-EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_sum_f32")
+EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_sum_f32", "uavagent_first_layer_f32",
+           "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
+           "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
+           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_rmsprop_tf1")
+ABI_VERSION = 2
 
 _lib = None
+_P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
 
 class UavAgentError(RuntimeError):
@@ -36,10 +40,28 @@ def load():
     lib = C.CDLL(path)
     lib.uavagent_abi_version.restype = C.c_int
     lib.uavagent_last_error.restype = C.c_char_p
-    lib.uavagent_sparse_rows_sum_f32.restype = C.c_int
-    lib.uavagent_sparse_rows_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
-    if lib.uavagent_abi_version() != 1:
+    sig = {
+        "uavagent_sparse_rows_sum_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _P],
+        "uavagent_first_layer_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _I32, _P],
+        "uavagent_obs_indices": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
+        "uavagent_sample_actions": [_P, _P, _I64, _I32, _P, _P, _P],
+        "uavagent_a2c_loss_grad": [_P, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P],
+        "uavagent_relu6_bwd": [_P, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P],
+        "uavagent_rowdot_f32": [_P, _P, _P, _I64, _I32, _P, _P],
+        "uavagent_rows_grad_f32": [_P, _P, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, C.c_size_t, _P],
+        "uavagent_rmsprop_tf1": [_P, _P, _P, _I64, _F, _F, _F, _F, _P],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    lib.uavagent_loss_grad_workspace_bytes.restype = C.c_size_t
+    lib.uavagent_loss_grad_workspace_bytes.argtypes = [_I32]
+    lib.uavagent_relu6_bwd_workspace_bytes.restype = C.c_size_t
+    lib.uavagent_relu6_bwd_workspace_bytes.argtypes = [_I32]
+    lib.uavagent_rows_grad_workspace_bytes.restype = C.c_size_t
+    lib.uavagent_rows_grad_workspace_bytes.argtypes = [_I64, _I32, _I32, _I64]
+    if lib.uavagent_abi_version() != ABI_VERSION:
         raise UavAgentError("libuavagent.so ABI version mismatch")
     _lib = lib
     return lib
@@ -49,7 +71,21 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def sparse_rows_sum(idx, w_a, b_a, w_c=None, b_c=None):
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise UavAgentError("%s: %s" % (what, load().uavagent_last_error().decode()))
+
+
+def _f32c(t, what):
+    if t is not None and (t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous()):
+        raise UavAgentError("%s must be a contiguous float32 CUDA tensor" % what)
+
+
+def sparse_rows_sum(idx, w_a, b_a, w_c=None, b_c=None, relu6=False, out_a=None, out_c=None):
     """Raw launch, no autograd: returns out_a or (out_a, out_c).  idx int64 [M, K]; w_* f32 [S, H]; b_* f32 [H] or None."""
     lib = load()
     if not (idx.is_cuda and w_a.is_cuda):
@@ -67,15 +103,114 @@ def sparse_rows_sum(idx, w_a, b_a, w_c=None, b_c=None):
     b_a = None if b_a is None else b_a.contiguous()
     b_c = None if b_c is None else b_c.contiguous()
     (M, K), (S, H) = idx.shape, w_a.shape
-    out_a = torch.empty((M, H), dtype=torch.float32, device=idx.device)
-    out_c = None if w_c is None else torch.empty((M, H), dtype=torch.float32, device=idx.device)
+    if out_a is None:
+        out_a = torch.empty((M, H), dtype=torch.float32, device=idx.device)
+    if w_c is not None and out_c is None:
+        out_c = torch.empty((M, H), dtype=torch.float32, device=idx.device)
+    for o in (out_a, out_c):
+        if o is not None and (o.shape != (M, H) or o.dtype != torch.float32 or not o.is_contiguous()):
+            raise UavAgentError("outputs must be contiguous float32 [M, H]")
     with torch.cuda.device(idx.device):
-        stream = C.c_void_p(torch.cuda.current_stream(idx.device).cuda_stream)
-        rc = lib.uavagent_sparse_rows_sum_f32(_ptr(w_a), _ptr(b_a), _ptr(out_a), _ptr(w_c), _ptr(b_c), _ptr(out_c), _ptr(idx),
-                                              M, K, H, S, stream)
-    if rc != 0:
-        raise UavAgentError("uavagent_sparse_rows_sum_f32: %s" % lib.uavagent_last_error().decode())
+        rc = lib.uavagent_first_layer_f32(_ptr(w_a), _ptr(b_a), _ptr(out_a), _ptr(w_c), _ptr(b_c), _ptr(out_c), _ptr(idx),
+                                          M, K, H, S, 1 if relu6 else 0, _stream(idx.device))
+    _check(rc, "uavagent_first_layer_f32")
     return out_a if w_c is None else (out_a, out_c)
+
+
+def obs_indices(obs, grid_n, n_bs, out=None):
+    """agent.obs_to_indices on the device in one launch: obs = env.observation() (ue_xy i16, bs_xy i32, serving i8)."""
+    ue, bs, srv = obs["ue_xy"], obs["bs_xy"], obs["serving"]
+    if ue.dtype != torch.int16 or bs.dtype != torch.int32 or srv.dtype != torch.int8:
+        raise UavAgentError("obs_indices needs the env's compact observation dtypes (int16 / int32 / int8)")
+    N, U, B = ue.shape[0], ue.shape[1], bs.shape[1]
+    if B != n_bs:
+        raise UavAgentError("n_bs does not match bs_xy")
+    if out is None:
+        out = torch.empty((N, B + U), dtype=torch.int64, device=ue.device)
+    elif out.shape != (N, B + U) or out.dtype != torch.int64 or not out.is_contiguous():
+        raise UavAgentError("out must be contiguous int64 [N, B + U]")
+    with torch.cuda.device(ue.device):
+        rc = load().uavagent_obs_indices(_ptr(ue.contiguous()), _ptr(bs.contiguous()), _ptr(srv.contiguous()), N, U, B, int(grid_n),
+                                         _ptr(out), _stream(ue.device))
+    _check(rc, "uavagent_obs_indices")
+    return out
+
+
+def sample_actions(logits, uniforms, out=None, prob_out=None):
+    """softmax + inverse-CDF draw per row (main.py:165-169) with caller-supplied uniforms [N]."""
+    _f32c(logits, "logits")
+    _f32c(uniforms, "uniforms")
+    N, A = logits.shape
+    if uniforms.numel() != N:
+        raise UavAgentError("one uniform per row")
+    if out is None:
+        out = torch.empty((N,), dtype=torch.int64, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = load().uavagent_sample_actions(_ptr(logits), _ptr(uniforms), N, A, _ptr(out), _ptr(prob_out), _stream(logits.device))
+    _check(rc, "uavagent_sample_actions")
+    return out
+
+
+def rowdot(y, w, b, out):
+    _f32c(y, "y")
+    with torch.cuda.device(y.device):
+        rc = load().uavagent_rowdot_f32(_ptr(y), _ptr(w), _ptr(b), y.shape[0], y.shape[1], _ptr(out), _stream(y.device))
+    _check(rc, "uavagent_rowdot_f32")
+    return out
+
+
+def loss_grad_workspace(n_actions, device):
+    return torch.empty(load().uavagent_loss_grad_workspace_bytes(int(n_actions)), dtype=torch.uint8, device=device)
+
+
+def a2c_loss_grad(logits, v, target, actions, beta, dv_out, dbias_out, loss_out, ws):
+    """In place: logits <- d a_loss / d logits.  loss_out: float64 [3] = (a_loss, c_loss, sum dv)."""
+    _f32c(logits, "logits")
+    M, A = logits.shape
+    with torch.cuda.device(logits.device):
+        rc = load().uavagent_a2c_loss_grad(_ptr(logits), _ptr(v), _ptr(target), _ptr(actions), M, A, float(beta), _ptr(dv_out),
+                                           _ptr(dbias_out), _ptr(loss_out), _ptr(ws), _stream(logits.device))
+    _check(rc, "uavagent_a2c_loss_grad")
+
+
+def relu6_bwd_workspace(n_cols, device):
+    return torch.empty(load().uavagent_relu6_bwd_workspace_bytes(int(n_cols)), dtype=torch.uint8, device=device)
+
+
+def relu6_bwd(dy, y, dx_out, ldx, dbias_out, ws, dv=None, w3=None, dw3_out=None):
+    """dx = dy * (0 < y < 6) + column sums; dy=None: the critic head form (dy = dv x w3)."""
+    _f32c(y, "y")
+    M, Cn = y.shape
+    with torch.cuda.device(y.device):
+        rc = load().uavagent_relu6_bwd(_ptr(dy), _ptr(y), _ptr(dv), _ptr(w3), M, Cn, _ptr(dx_out), int(ldx), _ptr(dbias_out),
+                                       _ptr(dw3_out), _ptr(ws), _stream(y.device))
+    _check(rc, "uavagent_relu6_bwd")
+
+
+def rows_grad_workspace(m_rows, k, n_cols_total, n_rows, device):
+    n = load().uavagent_rows_grad_workspace_bytes(int(m_rows), int(k), int(n_cols_total), int(n_rows))
+    if n == 0:
+        raise UavAgentError("uavagent_rows_grad_workspace_bytes: %s" % load().uavagent_last_error().decode())
+    return torch.empty(n + 256, dtype=torch.uint8, device=device)
+
+
+def rows_grad(idx, g, h, n_rows, dw0, dw1, ws):
+    """dw[r] = sum of g[m] over pairs idx[m, k] == r (deterministic sort + segmented sum).  g: [M, h] or [M, 2h]."""
+    _f32c(g, "g")
+    M, K = idx.shape
+    n_tables = g.shape[1] // h
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(g.device):
+        rc = load().uavagent_rows_grad_f32(_ptr(idx), _ptr(g), M, K, int(h), n_tables, int(n_rows), _ptr(dw0), _ptr(dw1),
+                                           C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream(g.device))
+    _check(rc, "uavagent_rows_grad_f32")
+
+
+def rmsprop_tf1(w, ms, g, lr, decay=0.9, eps=1e-10, g_scale=1.0):
+    with torch.cuda.device(w.device):
+        rc = load().uavagent_rmsprop_tf1(_ptr(w), _ptr(ms), _ptr(g), w.numel(), float(lr), float(decay), float(eps), float(g_scale),
+                                         _stream(w.device))
+    _check(rc, "uavagent_rmsprop_tf1")
 
 
 _bag_cache = {}
@@ -93,14 +228,8 @@ def _bags(M, K, device):
     return _bag_cache[key]
 
 
-def _bias_grad(g):
-    """Column sums of g [M, H].  Measured alternatives that did NOT help (tools/profile_a2c.py, 65536 x 200): torch.mv(g.t(), ones)
-    runs rocBLAS gemv at 614 us per call, twice as slow; a two-stage slab reduction changes nothing.  (The 288 us column
-    reductions that stand out in the update profile are autograd's own bias gradients of the hidden layers, not these.)"""
-    return g.sum(dim=0)
-
-
-def _table_grad(g, idx, n_rows):
+def _table_grad_aten(g, idx, n_rows):
+    """ATen's own embedding_bag backward (what autograd runs for the reference form): the comparison target of rows_grad."""
     o2b, size, max_idx = _bags(idx.shape[0], idx.shape[1], idx.device)
     flat = idx.reshape(-1)
     keep = (flat >= 0).to(g.dtype)                # -1 = "no row" (agent.obs_to_indices): no gradient, as in first_layer_reference
@@ -109,10 +238,14 @@ def _table_grad(g, idx, n_rows):
 
 
 class _SparseRowsSum(torch.autograd.Function):
+    """Differentiable first layer for the autograd (reference) path of the learner: forward = the HIP gather kernel, backward =
+    uavagent_rows_grad_f32 for both tables in one sorted pass + plain column sums for the biases."""
+
     @staticmethod
     def forward(ctx, idx, w_a, b_a, w_c, b_c):
         ctx.save_for_backward(idx)
         ctx.n_rows = w_a.shape[0]
+        ctx.h = w_a.shape[1]
         ctx.two = w_c is not None
         out = sparse_rows_sum(idx, w_a, b_a, w_c, b_c)
         if ctx.two:
@@ -123,10 +256,16 @@ class _SparseRowsSum(torch.autograd.Function):
     def backward(ctx, g_a, g_c):
         (idx,) = ctx.saved_tensors
         need = ctx.needs_input_grad            # (idx, w_a, b_a, w_c, b_c)
-        gw_a = _table_grad(g_a, idx, ctx.n_rows) if need[1] else None
-        gb_a = _bias_grad(g_a) if need[2] else None
-        gw_c = _table_grad(g_c, idx, ctx.n_rows) if (ctx.two and need[3]) else None
-        gb_c = _bias_grad(g_c) if (ctx.two and need[4]) else None
+        two = ctx.two and g_c is not None
+        gw_a = gw_c = None
+        if need[1] or (two and need[3]):
+            g = torch.cat([g_a, g_c], dim=1).contiguous() if two else g_a.contiguous()
+            gw_a = torch.empty((ctx.n_rows, ctx.h), dtype=torch.float32, device=g.device)
+            gw_c = torch.empty_like(gw_a) if two else None
+            ws = rows_grad_workspace(idx.shape[0], idx.shape[1], g.shape[1], ctx.n_rows, g.device)
+            rows_grad(idx.contiguous(), g, ctx.h, ctx.n_rows, gw_a, gw_c, ws)
+        gb_a = g_a.sum(dim=0) if need[2] else None
+        gb_c = g_c.sum(dim=0) if (two and need[4]) else None
         return None, gw_a, gb_a, gw_c, gb_c
 
 

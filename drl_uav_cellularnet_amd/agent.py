@@ -148,7 +148,8 @@ class TFRMSProp:
 
     def zero_grad(self):
         for p in self.params:
-            p.grad = None
+            if p.grad is not None:
+                p.grad.zero_()          # keeps FlatParams' gradient views in place
 
     def state_dict(self):
         return {"ms": [m.clone() for m in self.ms], "lr": self.lr, "decay": self.decay, "eps": self.eps}
@@ -189,79 +190,278 @@ def allreduce_mean_grads(params):
     return n
 
 
-def sample_actions(prob, generator=None):
+def sample_actions(prob, generator=None, uniforms=None):
     """One action per row of ``prob`` [N, n_action], the way the reference draws it (main.py:167-168):
     np.random.choice(range(n), p=p) is cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, uniform, side='right').
     Same three steps on the device (one uniform per env from ``generator``); a third of the time of torch.multinomial at
     [8192, 625] (tools/profile_a2c.py).  An action of probability 0 is never drawn; the result is always < n_action."""
     cdf = prob.cumsum(dim=1)
-    u = torch.rand((prob.shape[0], 1), device=prob.device, dtype=prob.dtype, generator=generator) * cdf[:, -1:]
+    if uniforms is None:
+        uniforms = torch.rand((prob.shape[0], 1), device=prob.device, dtype=prob.dtype, generator=generator)
+    u = uniforms.reshape(-1, 1).to(prob.dtype) * cdf[:, -1:]
     return torch.searchsorted(cdf, u, right=True).squeeze(1).clamp_(max=prob.shape[1] - 1)
+
+
+PARAM_ORDER = ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "c_w1", "c_b1", "c_w2", "c_b2", "c_w3", "c_b3")
+N_ACTOR_PARAMS = 6
+
+
+class FlatParams:
+    """All parameters of an ACNet as views of ONE flat float32 buffer, their gradients as views of a second one and the RMSProp
+    mean squares in a third (every view starts on a 256-byte boundary; the padding stays zero).  One buffer = one all-reduce
+    with no gather / scatter copies, one fused optimiser launch per trunk, one memset to clear the gradients.  Autograd
+    accumulates into the existing .grad views in place, so the reference (autograd) path fills the same buffer."""
+
+    ALIGN = 64   # floats
+
+    def __init__(self, net):
+        params = [getattr(net, k) for k in PARAM_ORDER]
+        dev = params[0].device
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.n_flat = off
+        self.n_real = sum(p.numel() for p in params)
+        self.actor_end = offs[N_ACTOR_PARAMS]               # [0, actor_end) actor trunk, [actor_end, n_flat) critic trunk
+        self.w = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.ms = torch.ones(off, dtype=torch.float32, device=dev)    # TF1: accumulator initialised to ones (main.py:300-301)
+        self.gv = {}
+        with torch.no_grad():
+            for k, p, o in zip(PARAM_ORDER, params, offs):
+                view = self.w[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                p.grad = self.g[o:o + p.numel()].view_as(p)
+                self.gv[k] = p.grad
+
+    def zero_grad(self):
+        self.g.zero_()
 
 
 class A2CRunner:
     """Synchronous A2C over a BatchedMobiEnv: every env instance plays the role of one of the reference's workers
-    (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step."""
+    (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step.
+
+    On a GPU the rollout loop is ONE hipGraph (per step: first layer + two GEMMs + sampling kernel + env step + index kernel)
+    and the update is a hand-derived backward pass: PyTorch GEMMs for the dense layers, libuavagent kernels for everything
+    around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs"):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True):
         self.env = env
         self.dev = env.device
         self.G, self.B = env.grid_n, env.nBS
         self.net = (net if net is not None else ACNet(env.observation_space_dim, env.action_space_dim, seed=seed)).to(self.dev)
-        self.opt_a = TFRMSProp(self.net.actor_params(), lr_a)
+        self.flat = FlatParams(self.net)
+        self.lr_a, self.lr_c = float(lr_a), float(lr_c)
+        self.opt_a = TFRMSProp(self.net.actor_params(), lr_a)       # reference path only; shares FlatParams' accumulators
         self.opt_c = TFRMSProp(self.net.critic_params(), lr_c)
+        for opt, keys in ((self.opt_a, PARAM_ORDER[:N_ACTOR_PARAMS]), (self.opt_c, PARAM_ORDER[N_ACTOR_PARAMS:])):
+            opt.ms = [self._ms_view(k) for k in keys]
         self.T, self.gamma, self.beta = int(rollout), float(gamma), float(beta)
         self.update_chunk = int(update_chunk)
         self.gen = torch.Generator(device=self.dev).manual_seed(int(seed) + 1000 * int(env.env_id_base + 1))
+        if first_state not in ("obs", "zeros"):
+            raise ValueError("first_state must be 'obs' or 'zeros'")
+        if collect_launch not in ("graph", "eager"):
+            raise ValueError("collect_launch must be 'graph' or 'eager'")
+        self.collect_launch = collect_launch
+        self.fused_update = bool(fused_update)
+        N, T, K = env.n_envs, self.T, env.nBS + env.nUE
+        # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
+        # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
+        self.idx_buf = torch.empty((T + 1, N, K), dtype=torch.int64, device=self.dev)
+        self.act_buf = torch.empty((T, N), dtype=torch.int64, device=self.dev)
+        self.rew_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
+        self.u_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
         # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
         # every index is -1 = "no row" and the first layer returns its bias.
-        if first_state not in ("obs", "zeros"):
-            raise ValueError("first_state must be 'obs' or 'zeros'")
-        self.idx = obs_to_indices(env.observation(), self.G, self.B)
+        self.idx_buf[T] = obs_to_indices(env.observation(), self.G, self.B)
         if first_state == "zeros":
-            self.idx = torch.full_like(self.idx, -1)
-        self.ep_r = torch.zeros(env.n_envs, device=self.dev)
+            self.idx_buf[T].fill_(-1)
+        self.ep_r = torch.zeros(N, device=self.dev)
         self.running_r = None                                          # GLOBAL_RUNNING_R EMA, :169-172
         self.stats = {}
+        self._graph = None
+        self._upd = None
+
+    def _ms_view(self, key):
+        p = getattr(self.net, key)
+        off = (p.data_ptr() - self.flat.w.data_ptr()) // 4
+        return self.flat.ms[off:off + p.numel()].view_as(p)
+
+    @property
+    def idx(self):
+        """Indices of the current observation [N, B + U] (what the next action will be chosen from)."""
+        return self.idx_buf[self.T]
+
+    # ---- rollout ---------------------------------------------------------------------------------------------------
+    def _indices_into(self, out):
+        if self.dev.type == "cuda":
+            from . import _agent_capi as A
+
+            A.obs_indices(self.env.observation(), self.G, self.B, out=out)
+        else:
+            out.copy_(obs_to_indices(self.env.observation(), self.G, self.B))
+
+    def _rollout_steps(self):
+        """The T-step loop: choose_action (main.py:165-169) -> env.step -> next observation.  No host synchronisation, no
+        allocation visible to the caller: capturable."""
+        env, T, net = self.env, self.T, self.net
+        self.idx_buf[0].copy_(self.idx_buf[T])
+        cuda = self.dev.type == "cuda"
+        if cuda:
+            from . import _agent_capi as A
+        for t in range(T):
+            if cuda:
+                h1 = A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, relu6=True)
+                h2 = torch.addmm(net.a_b2, h1, net.a_w2).clamp_(0.0, 6.0)
+                logits = torch.addmm(net.a_b3, h2, net.a_w3)
+                A.sample_actions(logits, self.u_buf[t], out=self.act_buf[t])
+            else:
+                prob = net.actor_only(self.idx_buf[t])
+                self.act_buf[t] = sample_actions(prob, uniforms=self.u_buf[t])
+            env.step(self.act_buf[t], reward_out=self.rew_buf[t])
+            self._indices_into(self.idx_buf[t + 1])
 
     @torch.no_grad()
     def collect(self):
-        """One rollout: returns (idx [T,N,K], actions [T,N], rewards [T,N], bootstrap [N])."""
-        env, T, N = self.env, self.T, self.env.n_envs
-        K = self.idx.shape[1]
-        idx_buf = torch.empty((T, N, K), dtype=torch.int64, device=self.dev)
-        act_buf = torch.empty((T, N), dtype=torch.int64, device=self.dev)
-        rew_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
-        done = None
-        for t in range(T):
-            prob = self.net.actor_only(self.idx)                                     # choose_action, main.py:165-169
-            a = sample_actions(prob, self.gen)
-            idx_buf[t], act_buf[t] = self.idx, a
-            obs, reward, done, _ = env.step(a)
-            rew_buf[t] = reward
-            self.idx = obs_to_indices(obs, self.G, self.B)
-        self.ep_r += rew_buf.sum(dim=0)
-        done = done.bool()
-        boot = self.net.critic_only(self.idx).squeeze(1)                             # :173-176
+        """One rollout: returns (idx [T,N,K], actions [T,N], rewards [T,N], bootstrap [N]) -- views of persistent buffers, valid
+        until the next collect()."""
+        env, T = self.env, self.T
+        self.u_buf.copy_(torch.rand(self.u_buf.shape, device=self.dev, dtype=torch.float32, generator=self.gen))
+        if self.collect_launch == "graph" and self.dev.type == "cuda":
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._rollout_steps()
+        self.ep_r += self.rew_buf.sum(dim=0)
+        done = env.out["done"].bool()
+        boot = self.net.critic_only(self.idx_buf[T]).squeeze(1)                      # :173-176
         boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
         if bool(done.any()):                                                         # :167-172 reset_worker
             m = float(self.ep_r[done].mean())
             self.running_r = m if self.running_r is None else 0.99 * self.running_r + 0.01 * m
             self.ep_r[done] = 0.0
             env.reset(mask=done)
-            self.idx = obs_to_indices(env.observation(), self.G, self.B)
-        return idx_buf, act_buf, rew_buf, boot
+            self._indices_into(self.idx_buf[T])
+        return self.idx_buf[:T], self.act_buf, self.rew_buf, boot
 
+    def _capture(self):
+        """hipGraph of the rollout loop.  A warm-up pass on a side stream first (rocBLAS handles / workspaces), on a CLONE of the
+        env state so that capturing changes nothing the caller can observe."""
+        env = self.env
+        state = torch.empty(env._lay.total_bytes, dtype=torch.uint8, device=self.dev)
+        env.copy_state_to(state)
+        keep = {k: v.clone() for k, v in env.out.items()}
+        keep_idx = self.idx_buf[self.T].clone()
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            self._rollout_steps()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        env.copy_state_from(state)
+        for k, v in keep.items():
+            env.out[k].copy_(v)
+        self.idx_buf[self.T].copy_(keep_idx)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._rollout_steps()
+        self._graph = g
+
+    # ---- update ----------------------------------------------------------------------------------------------------
     def update(self, idx_buf, act_buf, rew_buf, boot):
-        """One gradient step on all T*N samples (a2c_single_thread.py:120-133), chunked to bound activation memory."""
+        """One gradient step on all T*N samples (a2c_single_thread.py:120-133)."""
+        if self.fused_update and self.dev.type == "cuda":
+            return self.update_fused(idx_buf, act_buf, rew_buf, boot)
+        return self.update_reference(idx_buf, act_buf, rew_buf, boot)
+
+    def _allreduce(self):
+        """Mean of the flat gradient over ranks: ONE all-reduce (RCCL over xGMI with backend nccl) straight on the buffer the
+        backward pass wrote; the 1 / world_size is folded into the optimiser step.  -> (elements reduced, g_scale)."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self.flat.n_real, 1.0
+        dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM)
+        return self.flat.n_real, 1.0 / dist.get_world_size()
+
+    def _ensure_update_buffers(self, M, K):
+        from . import _agent_capi as A
+
+        if self._upd is not None and self._upd["M"] == M:
+            return self._upd
+        H, NA, dev = HIDDEN, self.net.n_action, self.dev
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self._upd = {"M": M, "h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H), "h2c": f(M, H), "dh": f(M, H), "logits": f(M, NA),
+                     "gcat": f(M, 2 * H), "v": f(M), "dv": f(M), "loss": torch.zeros(3, dtype=torch.float64, device=dev),
+                     "ws_loss": A.loss_grad_workspace(NA, dev), "ws_relu": A.relu6_bwd_workspace(H, dev),
+                     "ws_rows": A.rows_grad_workspace(M, K, 2 * H, self.net.n_state, dev)}
+        return self._upd
+
+    @torch.no_grad()
+    def update_fused(self, idx_buf, act_buf, rew_buf, boot):
+        """The update with a hand-derived backward pass (same mathematics as update_reference, main.py:64-74,143-156):
+        dense layers = torch GEMMs writing straight into the flat gradient buffer; softmax / loss / its gradient, relu6
+        backward + bias gradients, the value head, the table gradient and RMSProp = libuavagent kernels."""
+        from . import _agent_capi as A
+
+        net, fl = self.net, self.flat
+        T, N, K = idx_buf.shape
+        M, H = T * N, HIDDEN
+        target = nstep_returns(rew_buf, boot, self.gamma).reshape(M)
+        idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
+        b = self._ensure_update_buffers(M, K)
+        gv = fl.gv
+        # forward
+        A.sparse_rows_sum(idx, net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=b["h1a"], out_c=b["h1c"])
+        torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
+        torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
+        torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
+        A.rowdot(b["h2c"], net.c_w3, net.c_b3, b["v"])
+        # loss and its gradient w.r.t. logits / v (logits are overwritten); d a_b3, d c_b3
+        A.a2c_loss_grad(b["logits"], b["v"], target, act, self.beta, b["dv"], gv["a_b3"], b["loss"], b["ws_loss"])
+        gv["c_b3"].copy_(b["loss"][2:3].to(torch.float32))
+        # actor trunk backwards
+        torch.mm(b["h2a"].t(), b["logits"], out=gv["a_w3"])
+        torch.mm(b["logits"], net.a_w3.t(), out=b["dh"])
+        A.relu6_bwd(b["dh"], b["h2a"], b["dh"], H, gv["a_b2"], b["ws_relu"])
+        torch.mm(b["h1a"].t(), b["dh"], out=gv["a_w2"])
+        torch.mm(b["dh"], net.a_w2.t(), out=b["h2a"])                 # h2a is free now: reuse it for d h1a
+        A.relu6_bwd(b["h2a"], b["h1a"], b["gcat"], 2 * H, gv["a_b1"], b["ws_relu"])
+        # critic trunk backwards
+        A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
+        torch.mm(b["h1c"].t(), b["dh"], out=gv["c_w2"])
+        torch.mm(b["dh"], net.c_w2.t(), out=b["h2c"])
+        A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
+        # first-layer tables: both in one sorted pass
+        A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
+        # synchronise and step
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        n_red, g_scale = self._allreduce()
+        ev1.record()
+        ae = fl.actor_end
+        A.rmsprop_tf1(fl.w[:ae], fl.ms[:ae], fl.g[:ae], self.lr_a, g_scale=g_scale)
+        A.rmsprop_tf1(fl.w[ae:], fl.ms[ae:], fl.g[ae:], self.lr_c, g_scale=g_scale)
+        loss = b["loss"].cpu()                                        # (synchronises)
+        self.stats = {"a_loss": float(loss[0]), "c_loss": float(loss[1]), "mean_reward": float(rew_buf.mean()),
+                      "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1)}
+        return self.stats
+
+    def update_reference(self, idx_buf, act_buf, rew_buf, boot):
+        """The same update through autograd (the form round 1 shipped), chunked to bound activation memory; gradients
+        accumulate into the flat buffer, TFRMSProp steps on views of the same flat accumulators."""
         T, N, K = idx_buf.shape
         target = nstep_returns(rew_buf, boot, self.gamma).reshape(T * N, 1)
         idx, act = idx_buf.reshape(T * N, K), act_buf.reshape(T * N)
         M = T * N
-        self.opt_a.zero_grad()
-        self.opt_c.zero_grad()
+        self.flat.zero_grad()
         a_tot = c_tot = 0.0
         for s in range(0, M, self.update_chunk):
             e = min(M, s + self.update_chunk)
@@ -271,15 +471,13 @@ class A2CRunner:
             ((a_loss + c_loss) * w).backward()                # disjoint parameter sets: same grads as two backward()s
             a_tot += float(a_loss.detach()) * w
             c_tot += float(c_loss.detach()) * w
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        n_red = allreduce_mean_grads(self.net.actor_params() + self.net.critic_params())
-        ev1.record()
+        n_red, g_scale = self._allreduce()
+        if g_scale != 1.0:
+            self.flat.g.mul_(g_scale)
         self.opt_a.step()
         self.opt_c.step()
         self.stats = {"a_loss": a_tot, "c_loss": c_tot, "mean_reward": float(rew_buf.mean()), "grad_elems": n_red,
-                      "running_r": self.running_r}
-        self.stats["allreduce_ms"] = ev0.elapsed_time(ev1)     # (float(...) above has synchronised)
+                      "running_r": self.running_r, "allreduce_ms": None}
         return self.stats
 
     def train_rollout(self):
@@ -318,6 +516,7 @@ def load_actor_npz(net, path):
 
 
 def grad_allreduce_bytes(net):
+    """Bytes of real gradient per all-reduce (the flat buffer adds < 1 KB of alignment padding)."""
     return 4 * sum(p.numel() for p in net.parameters())
 
 

@@ -180,7 +180,7 @@ class BatchedMobiEnv:
                                                  self._out_ref, self._stream()))
         return self.observation()
 
-    def step(self, actions, theta_u=None, group_u=None, fading=None):
+    def step(self, actions, theta_u=None, group_u=None, fading=None, reward_out=None):
         """MobiEnvironment.step (mobile_env.py:150-194): returns (obs, reward, done, info).
 
         ``actions``: int64 tensor [N] on this device, each in [0, 5**nBS) (base-5 digits, most significant
@@ -189,10 +189,20 @@ class BatchedMobiEnv:
         a = self._actions(actions)
         inj = None if (theta_u is None and group_u is None and fading is None) else self._inject(theta_u, group_u,
                                                                                                  fading)
-        rc = self._lib.uavenv_step(self._h, a.data_ptr(), inj, self._out_ref, self._stream())
+        out_ref = self._out_ref
+        if reward_out is not None:       # this step's reward straight into the caller's rollout buffer (float32 [N], contiguous)
+            if reward_out.dtype != torch.float32 or reward_out.numel() != self.n_envs or not reward_out.is_contiguous():
+                raise ValueError("reward_out must be a contiguous float32 [n_envs] tensor")
+            st = _capi.UavEnvOut.from_buffer_copy(self._out_struct)
+            st.reward_dev = reward_out.data_ptr()
+            out_ref = C.byref(st)
+        rc = self._lib.uavenv_step(self._h, a.data_ptr(), inj, out_ref, self._stream())
         if rc:
             _capi.check(rc)
         o = self.out
+        if reward_out is not None:
+            return self.observation(), reward_out, o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
+                                                               "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
         return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
                                                              "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
 
@@ -317,6 +327,13 @@ class BatchedMobiEnv:
         if blob.size != self._lay.total_bytes:
             raise ValueError("state blob has the wrong size")
         _capi.check(self._lib.uavenv_set_state(self._h, blob.ctypes.data, 0, self._stream()))
+
+    def copy_state_to(self, dev_buf):
+        """Device-to-device snapshot of the state blob into a uint8 tensor of _lay.total_bytes (stream-ordered, no sync)."""
+        _capi.check(self._lib.uavenv_get_state(self._h, dev_buf.data_ptr(), 1, self._stream()))
+
+    def copy_state_from(self, dev_buf):
+        _capi.check(self._lib.uavenv_set_state(self._h, dev_buf.data_ptr(), 1, self._stream()))
 
     def state_fields(self, blob=None):
         """The state blob decoded into named arrays (record formats: UavEnvStateLayout in include/uavenv.h).  Field views

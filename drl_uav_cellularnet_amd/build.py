@@ -16,8 +16,9 @@ DEPS = [SRC] + [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "
     os.path.join(ROOT, "include", "uavenv.h")]
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libuavenv.so")
-AGENT_SRC = os.path.join(PKG_DIR, "csrc", "agent_kernels.hip")
-AGENT_DEPS = [AGENT_SRC, os.path.join(ROOT, "include", "uavagent.h")]
+AGENT_SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("agent_kernels.hip", "agent_learner.hip")]
+AGENT_SRC = AGENT_SRCS[0]
+AGENT_DEPS = AGENT_SRCS + [os.path.join(PKG_DIR, "csrc", "agent_common.h"), os.path.join(ROOT, "include", "uavagent.h")]
 AGENT_LIB = os.path.join(LIB_DIR, "libuavagent.so")
 ARCH = "gfx950"
 
@@ -45,7 +46,8 @@ def build_agent(force=False, verbose=False):
     if not force and not _stale(AGENT_LIB, AGENT_DEPS):
         return AGENT_LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-Wall", "-o", AGENT_LIB, AGENT_SRC]
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-o", AGENT_LIB] + AGENT_SRCS
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

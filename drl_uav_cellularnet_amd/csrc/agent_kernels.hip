@@ -13,11 +13,17 @@
 #include <string>
 
 #include "../../include/uavagent.h"
+#include "agent_common.h"
 
 namespace {
-
 thread_local std::string g_err;
+}
+namespace uavagent_internal {
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace uavagent_internal
+
+namespace {
+using uavagent_internal::fail;
 
 __device__ __forceinline__ void add4(float4 &s, const float4 &v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
 // s += v * w with w in {0.0f, 1.0f} held in an SGPR: one v_fmac per component, like the add it replaces; v * 1 + s rounds exactly
@@ -30,7 +36,13 @@ __device__ __forceinline__ float lane_weight(float w, int k) { return __int_as_f
 // KT > 0: K known at compile time (24 = 4 UAV + 20 UE, 44 = 4 + 40), so the row loop unrolls by UNR with no remainder --
 // v_readlane is a convergent operation and hipcc will not unroll a loop around it when the trip count is a run-time value.
 // KT == 0: any K, one row (per table) in flight at a time.
-template <bool TWO, int KT, int UNR>
+// RELU6: the layer's activation applied to the stored result, h = relu6(sum + b) (tf.nn.relu6, main.py:147-148,153): saves the
+// separate elementwise pass over [M, H] on both the acting and the update path.
+__device__ __forceinline__ float4 relu6_4(float4 v) {
+    v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+    return v;
+}
+template <bool TWO, int KT, int UNR, bool RELU6>
 __global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__restrict__ wa, const float *__restrict__ ba,
                                                               float *__restrict__ oa, const float *__restrict__ wc,
                                                               const float *__restrict__ bc, float *__restrict__ oc,
@@ -84,9 +96,11 @@ __global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__res
     if (!on) return;
     const unsigned long long o = (unsigned long long)m * row_bytes;
     if (ba != nullptr) add4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ba) + lane_off));
+    if (RELU6) sa = relu6_4(sa);
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(oa) + o + lane_off) = sa;
     if (TWO) {
         if (bc != nullptr) add4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(bc) + lane_off));
+        if (RELU6) sc = relu6_4(sc);
         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(oc) + o + lane_off) = sc;
     }
 }
@@ -95,12 +109,22 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
-extern "C" int uavagent_abi_version(void) { return 1; }
+extern "C" int uavagent_abi_version(void) { return 2; }
 extern "C" const char *uavagent_last_error(void) { return g_err.c_str(); }
+
+extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
+                                        const float *bias_c, float *out_c, const int64_t *idx, int64_t m_rows, int32_t k,
+                                        int32_t h, int64_t n_rows, int32_t relu6, void *stream);
 
 extern "C" int uavagent_sparse_rows_sum_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
                                             const float *bias_c, float *out_c, const int64_t *idx, int64_t m_rows, int32_t k,
                                             int32_t h, int64_t n_rows, void *stream) {
+    return uavagent_first_layer_f32(w_a, bias_a, out_a, w_c, bias_c, out_c, idx, m_rows, k, h, n_rows, 0, stream);
+}
+
+extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
+                                        const float *bias_c, float *out_c, const int64_t *idx, int64_t m_rows, int32_t k,
+                                        int32_t h, int64_t n_rows, int32_t relu6, void *stream) {
     if (m_rows < 0 || n_rows < 1 || k < 1 || k > 64) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: need m_rows >= 0, n_rows >= 1, 1 <= k <= 64");
     if (h < 4 || h > 256 || (h & 3)) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: h must be a multiple of 4 in [4, 256]");
     if ((unsigned long long)n_rows * (unsigned long long)h * 4ull > 0xFFFFFFFFull)
@@ -115,8 +139,12 @@ extern "C" int uavagent_sparse_rows_sum_f32(const float *w_a, const float *bias_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long *ix = reinterpret_cast<const long long *>(idx);
 #define UAVAGENT_LAUNCH(TWO_, KT_, UNR_)                                                                                  \
-    hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a, out_a, \
-                       w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows)
+    do {                                                                                                                  \
+        if (relu6) hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_, true>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a, \
+                                      out_a, w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows);           \
+        else hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_, false>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a,     \
+                                out_a, w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows);                 \
+    } while (0)
     if (w_c) {
         if (k == 24) UAVAGENT_LAUNCH(true, 24, 8);
         else if (k == 44) UAVAGENT_LAUNCH(true, 44, 4);

@@ -1,12 +1,18 @@
-/* C ABI of the one hand-written kernel on the learner side (libuavagent.so, gfx950).
+/* C ABI of the hand-written kernels on the learner side (libuavagent.so, gfx950).
  *
  * NOT part of the env drop-in boundary (that is uavenv.h).  The reference's actor and critic (main.py:143-156) start with a dense
  * layer on the raveled (nBS+1, G, G) state, 50 000 inputs of which nBS + nUE are non-zero (main.py:190,202).  On the batched path
  * that layer is a sum of nBS + nUE rows of a [N_S, H] table per sample; agent.py keeps the plain PyTorch form
- * (F.embedding_bag(idx, W, mode="sum") + b) as the reference implementation and the CPU path, and uses this kernel on the GPU.
+ * (F.embedding_bag(idx, W, mode="sum") + b) as the reference implementation and the CPU path, and uses these kernels on the GPU.
+ * The dense layers behind it stay PyTorch-ROCm GEMMs (north_star); ABI 2 adds the kernels around them: index construction and
+ * action sampling for the rollout, and for the update the fused loss gradient, relu6 backward with bias gradients, the table
+ * gradient (sorted, deterministic) and the TF1 RMSProp step.  Every entry point is asynchronous on `stream` (a hipStream_t,
+ * 0 = the null stream), allocates nothing (workspaces are caller-owned; *_workspace_bytes give their sizes), returns 0 or a
+ * negative UAVAGENT_E_* code and never throws; all pointers are device pointers on the current device.
  */
 #ifndef UAVAGENT_H
 #define UAVAGENT_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -17,21 +23,72 @@ extern "C" {
 #define UAVAGENT_E_INVALID (-1)
 #define UAVAGENT_E_HIP (-3)
 
-int uavagent_abi_version(void);
+int uavagent_abi_version(void);   /* 2 */
 const char *uavagent_last_error(void);
 
 /* out_a[m, :] = sum_k w_a[idx[m, k], :] + bias_a   (k ascending, fp32; bias added last, like embedding_bag(...) + b)
  * and, when w_c != NULL, the same for (w_c, bias_c, out_c) with the SAME indices: actor and critic read one index list.
- * All pointers are device pointers on the current device; rows are contiguous (row stride = h floats).
+ * Rows are contiguous (row stride = h floats).
  *   idx   int64 [m_rows, k]   each in [0, n_rows), or outside that range (by convention -1) = "no row": the entry adds nothing and
  *                             is never dereferenced (a faulting kernel can reset a shared GPU host).  An all -1 list yields the
  *                             bias: the reference's all-zero first state (a2c_single_thread.py:155)
  *   w_*   f32   [n_rows, h]   h % 4 == 0, 4 <= h <= 256, 16-byte aligned, n_rows * h * 4 < 4 GiB
  *   bias_* f32  [h] or NULL;  out_* f32 [m_rows, h], 16-byte aligned
- *   1 <= k <= 64.  `stream` is a hipStream_t (0 = the null stream).  Asynchronous. */
+ *   1 <= k <= 64. */
 int uavagent_sparse_rows_sum_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c, const float *bias_c,
                                  float *out_c, const int64_t *idx, int64_t m_rows, int32_t k, int32_t h, int64_t n_rows,
                                  void *stream);
+/* The same with the layer's activation fused when relu6 != 0: out = relu6(sum + bias)  (tf.nn.relu6, main.py:147-148,153). */
+int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c, const float *bias_c,
+                             float *out_c, const int64_t *idx, int64_t m_rows, int32_t k, int32_t h, int64_t n_rows,
+                             int32_t relu6, void *stream);
+
+/* Compact observation of the env (UavEnvOut: ue_xy i16 [N,U,2], bs_xy i32 [N,B,2], serving i8 [N,U]) -> flat indices of the
+ * non-zero cells of the reference's raveled (nBS+1, G, G) state (main.py:190,202): idx_out int64 [N, B+U], UAV cells (plane 0)
+ * first, then every UE in the plane of its serving UAV; a cell outside the grid becomes -1.  = agent.obs_to_indices. */
+int uavagent_obs_indices(const int16_t *ue_xy, const int32_t *bs_xy, const int8_t *serving, int64_t n_envs, int32_t n_ue,
+                         int32_t n_bs, int32_t grid, int64_t *idx_out, void *stream);
+
+/* choose_action (main.py:165-169): p = softmax(logits[n, :]); np.random.choice(n_actions, p=p) with the uniform u[n] supplied by
+ * the caller: the first a with cumsum(p)[a] > u[n] * cumsum(p)[-1].  logits f32 [n_rows, n_actions], uniforms f32 [n_rows] in
+ * [0, 1), actions_out int64 [n_rows]; prob_out f32 [n_rows, n_actions] or NULL.  n_actions <= 1024. */
+int uavagent_sample_actions(const float *logits, const float *uniforms, int64_t n_rows, int32_t n_actions, int64_t *actions_out,
+                            float *prob_out, void *stream);
+
+/* Loss of main.py:64-74 and its gradient, one pass.  IN: logits [m_rows, n_actions] (actor output before the softmax), v and
+ * v_target f32 [m_rows], actions int64 [m_rows].  OUT: logits_inout overwritten with d(a_loss)/d(logits); dv_out [m_rows] =
+ * d(c_loss)/dv; dbias_out [n_actions] = column sums of the logits gradient; loss_out double[3] = {a_loss, c_loss, sum(dv)}.
+ *   td = v_target - v;  c_loss = mean(td^2);  a_loss = mean(-(beta * H + log(p[a] + 1e-5) * td)),  H = -sum p log(p + 1e-5),
+ *   td enters a_loss as a constant (tf.stop_gradient, main.py:70). */
+size_t uavagent_loss_grad_workspace_bytes(int32_t n_actions);
+int uavagent_a2c_loss_grad(float *logits_inout, const float *v, const float *v_target, const int64_t *actions, int64_t m_rows,
+                           int32_t n_actions, float beta, float *dv_out, float *dbias_out, double *loss_out, void *workspace,
+                           void *stream);
+
+/* relu6 backwards with the bias gradient: dx[m, c] = dy[m, c] * (0 < y[m, c] < 6), dbias_out[c] = sum_m dx[m, c].
+ * y, dy f32 [m_rows, n_cols] contiguous; dx_out has row stride ldx floats (>= n_cols; lets two results share one [M, 2H] buffer).
+ * dy == NULL selects the critic's value head (v = h @ w3 + b3, main.py:155): dy[m, c] = dv[m] * w3[c] is formed on the fly and
+ * dw3_out[c] = sum_m y[m, c] * dv[m] is produced in the same pass.  n_cols % 4 == 0, <= 256. */
+size_t uavagent_relu6_bwd_workspace_bytes(int32_t n_cols);
+int uavagent_relu6_bwd(const float *dy, const float *y, const float *dv, const float *w3, int64_t m_rows, int32_t n_cols,
+                       float *dx_out, int64_t ldx, float *dbias_out, float *dw3_out, void *workspace, void *stream);
+
+/* out[m] = sum_c y[m, c] * w[c] + bias[0]: the critic's value head forwards (v = h @ w3 + b3, main.py:155) as one streaming pass.
+ * y f32 [m_rows, n_cols], w f32 [n_cols], bias f32 [1] or NULL, out f32 [m_rows]; n_cols % 4 == 0, <= 256. */
+int uavagent_rowdot_f32(const float *y, const float *w, const float *bias, int64_t m_rows, int32_t n_cols, float *out, void *stream);
+
+/* Gradient of the first-layer tables: dw[r, :] = sum of g[m, :] over all (m, k) with idx[m, k] == r; rows nobody references
+ * get 0, entries outside [0, n_rows) are skipped.  g f32 [m_rows, n_tables * h]: columns [0, h) belong to dw0_out, [h, 2h) to
+ * dw1_out (n_tables = 2: actor and critic share idx).  Stable sort by row + segmented sums in ascending sample order: the result
+ * is bit-reproducible (no float atomics).  Workspace: 256-byte aligned, uavagent_rows_grad_workspace_bytes(...) bytes. */
+size_t uavagent_rows_grad_workspace_bytes(int64_t m_rows, int32_t k, int32_t n_cols_total, int64_t n_rows);
+int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables,
+                           int64_t n_rows, float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* tf.train.RMSPropOptimizer(lr, decay, momentum = 0, epsilon) as TF1 applies it (main.py:300-301), on flat buffers of n floats:
+ *   gs = g * g_scale;  ms <- decay * ms + (1 - decay) * gs^2;  w <- w - lr * gs / sqrt(ms + epsilon). */
+int uavagent_rmsprop_tf1(float *w, float *ms, const float *g, int64_t n, float lr, float decay, float eps, float g_scale,
+                         void *stream);
 
 #ifdef __cplusplus
 }

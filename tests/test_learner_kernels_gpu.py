@@ -1,0 +1,241 @@
+"""GPU: the learner-side kernels of libuavagent.so (include/uavagent.h, ABI 2) against their plain PyTorch forms, and the fused
+A2C update / graph-captured rollout against the autograd / eager paths they replace.  The formulas are the reference's
+(main.py:64-74 loss, :143-156 network, :165-169 action choice, :300-301 RMSProp); TensorFlow is not installable here and the
+reference holds no fixtures for its learner, so this parity is against restatements: "parity unpinned" (DESIGN.md section 9)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def test_obs_indices_kernel_equals_obs_to_indices():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, _agent_capi as A
+    from drl_uav_cellularnet_amd.agent import obs_to_indices
+
+    env = BatchedMobiEnv(777, nBS=4, nUE=20, grid_n=100)
+    for t in range(3):
+        env.step(torch.randint(0, 625, (777,), device=env.device))
+    obs = {k: v.clone() for k, v in env.observation().items()}
+    obs["ue_xy"][5, 3, 0] = 100            # a walker exactly on x == G: no cell -> -1 in both
+    obs["ue_xy"][9, 0, 1] = -1
+    want = obs_to_indices(obs, 100, 4)
+    got = A.obs_indices(obs, 100, 4)
+    assert torch.equal(got, want)
+    assert int(got[5, 4 + 3]) == -1 and int(got[9, 4]) == -1 and int((got < 0).sum()) == 2
+
+
+def test_sample_actions_kernel_is_the_inverse_cdf_draw():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N, NA = 8192, 625
+    logits = torch.randn(N, NA, device="cuda", generator=g) * 3.0
+    logits[:, 17] = -1e30                                          # probability exactly 0: never drawn
+    u = torch.rand(N, device="cuda", generator=g)
+    u[0], u[1] = 0.0, 1.0 - 2 ** -24
+    prob = torch.empty_like(logits)
+    a = A.sample_actions(logits, u, prob_out=prob)
+    torch.testing.assert_close(prob, torch.softmax(logits, dim=1), rtol=1e-5, atol=1e-9)
+    p64 = torch.softmax(logits.double(), dim=1)
+    cdf = p64.cumsum(dim=1)
+    want = torch.searchsorted(cdf, (u.double() * cdf[:, -1]).unsqueeze(1), right=True).squeeze(1).clamp_(max=NA - 1)
+    diff = (a != want)
+    assert int(diff.sum()) <= 2                                    # float32 vs float64 CDF: only a draw ON a boundary may differ
+    if bool(diff.any()):
+        rows = diff.nonzero().squeeze(1)
+        lo = torch.minimum(a[rows], want[rows])
+        assert bool(((a[rows] - want[rows]).abs() <= 2).all())
+        assert bool(((cdf[rows, lo] - u[rows].double() * cdf[rows, -1]).abs() < 1e-6).all())
+    assert int((a == 17).sum()) == 0 and int(a.min()) >= 0 and int(a.max()) <= NA - 1
+    # small action counts take other per-lane widths
+    for na in (5, 64, 100, 1000):
+        lg = torch.randn(300, na, device="cuda", generator=g)
+        uu = torch.rand(300, device="cuda", generator=g)
+        got = A.sample_actions(lg, uu)
+        c = torch.softmax(lg.double(), dim=1).cumsum(dim=1)
+        ref = torch.searchsorted(c, (uu.double() * c[:, -1]).unsqueeze(1), right=True).squeeze(1).clamp_(max=na - 1)
+        assert int((got != ref).sum()) <= 1
+
+
+@pytest.mark.parametrize("shape", [(4096, 625), (1000, 5), (300, 100)])
+def test_loss_grad_kernel_matches_autograd(shape):
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+    from drl_uav_cellularnet_amd.agent import a2c_losses
+
+    M, NA = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    logits = (torch.randn(M, NA, device="cuda", generator=g) * 2).requires_grad_()
+    v = torch.randn(M, 1, device="cuda", generator=g).requires_grad_()
+    target = torch.randn(M, 1, device="cuda", generator=g)
+    act = torch.randint(0, NA, (M,), device="cuda", generator=g)
+    a_loss, c_loss = a2c_losses(torch.softmax(logits, dim=1), v, act, target, beta=0.001)
+    (a_loss + c_loss).backward()
+    work = logits.detach().clone()
+    dv = torch.empty(M, device="cuda")
+    db = torch.empty(NA, device="cuda")
+    loss = torch.zeros(3, dtype=torch.float64, device="cuda")
+    A.a2c_loss_grad(work, v.detach().reshape(M).contiguous(), target.reshape(M).contiguous(), act, 0.001, dv, db, loss,
+                    A.loss_grad_workspace(NA, "cuda"))
+    scale = float(logits.grad.abs().max())
+    torch.testing.assert_close(work, logits.grad, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(dv, v.grad.reshape(M), rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(db, logits.grad.sum(dim=0), rtol=1e-4, atol=1e-5 * float(logits.grad.sum(dim=0).abs().max()) + 1e-9)
+    np.testing.assert_allclose(loss.cpu().numpy()[:2], [float(a_loss), float(c_loss)], rtol=1e-5)
+    np.testing.assert_allclose(float(loss[2]), float(v.grad.sum()), rtol=1e-4, atol=1e-7)
+
+
+def test_relu6_bwd_and_value_head_kernels():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    M, H = 5000, 200
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = (torch.randn(M, H, device="cuda", generator=g) * 4).clamp_(0, 6)      # a relu6 output: zeros, interior, sixes
+    dy = torch.randn(M, H, device="cuda", generator=g)
+    ws = A.relu6_bwd_workspace(H, "cuda")
+    cat = torch.full((M, 2 * H), 7.0, device="cuda")
+    db = torch.empty(H, device="cuda")
+    A.relu6_bwd(dy, y, cat[:, H:], 2 * H, db, ws)
+    want = dy * ((y > 0) & (y < 6))
+    assert torch.equal(cat[:, H:], want) and bool((cat[:, :H] == 7.0).all())
+    torch.testing.assert_close(db, want.sum(dim=0), rtol=1e-4, atol=1e-4)
+    # value head: v = y @ w3 + b3
+    w3 = torch.randn(H, 1, device="cuda", generator=g) * 0.1
+    b3 = torch.randn(1, device="cuda", generator=g)
+    v = torch.empty(M, device="cuda")
+    A.rowdot(y, w3, b3, v)
+    torch.testing.assert_close(v, (y @ w3 + b3).reshape(M), rtol=1e-5, atol=1e-5)
+    dv = torch.randn(M, device="cuda", generator=g)
+    dx = torch.empty(M, H, device="cuda")
+    dw3 = torch.empty(H, 1, device="cuda")
+    A.relu6_bwd(None, y, dx, H, db, ws, dv=dv, w3=w3, dw3_out=dw3)
+    want = (dv.unsqueeze(1) * w3.t()) * ((y > 0) & (y < 6))
+    torch.testing.assert_close(dx, want, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(db, want.sum(dim=0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dw3, (y * dv.unsqueeze(1)).sum(dim=0).unsqueeze(1), rtol=1e-4, atol=1e-4)
+
+
+def _rows_grad_case(torch, A, idx, H, S, two):
+    M, K = idx.shape
+    g = torch.randn(M, (2 if two else 1) * H, device="cuda")
+    dw0 = torch.full((S, H), 9.0, device="cuda")
+    dw1 = torch.full((S, H), 9.0, device="cuda") if two else None
+    ws = A.rows_grad_workspace(M, K, g.shape[1], S, "cuda")
+    A.rows_grad(idx, g, H, S, dw0, dw1, ws)
+    ref0 = A._table_grad_aten(g[:, :H], idx, S)
+    tol = dict(rtol=1e-5, atol=1e-5 * max(1.0, float(ref0.abs().max())))
+    torch.testing.assert_close(dw0, ref0, **tol)
+    if two:
+        ref1 = A._table_grad_aten(g[:, H:], idx, S)
+        torch.testing.assert_close(dw1, ref1, rtol=1e-5, atol=1e-5 * max(1.0, float(ref1.abs().max())))
+    # float64 ground truth on a sample of rows, and bit-reproducibility
+    g64 = g[:, :H].double()
+    for r in torch.unique(idx[idx >= 0])[:5].tolist():
+        cnt = (idx == r).sum(dim=1).double()
+        torch.testing.assert_close(dw0[r].double(), (cnt.unsqueeze(1) * g64).sum(dim=0), rtol=1e-4, atol=1e-4)
+    again = torch.empty_like(dw0)
+    A.rows_grad(idx, g, H, S, again, torch.empty_like(dw0) if two else None, ws)
+    assert torch.equal(again, dw0)
+
+
+def test_rows_grad_matches_the_embedding_bag_backward():
+    """d loss / d W1 by sort + segmented sums against ATen's embedding_bag backward: uniform rows, a few HOT rows whose runs
+    cross many 512-pair chunks (every env's UAV on the same cell), 'no row' entries, one / two tables, small tables."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    S, H = 50000, 200
+    idx = torch.randint(0, S, (4096, 24), device="cuda", generator=gen)
+    _rows_grad_case(torch, A, idx, H, S, True)
+    idx = torch.randint(0, S, (6000, 24), device="cuda", generator=gen)
+    idx[:, 0] = 2525                                   # 6000 pairs of one row: 12 chunks
+    idx[:, 1] = 49999
+    idx[::2, 2] = 0
+    idx[::7, 5] = -1
+    idx[:3000, 6] = 31
+    _rows_grad_case(torch, A, idx, H, S, True)
+    idx = torch.full((40000, 3), 7, dtype=torch.int64, device="cuda")     # ONE row, 120000 pairs: 235 chunks (the gallop path)
+    idx[-1, 2] = 8
+    _rows_grad_case(torch, A, idx, 64, 100, False)
+    _rows_grad_case(torch, A, torch.randint(0, 37, (1000, 5), device="cuda", generator=gen), 8, 37, True)
+    _rows_grad_case(torch, A, torch.full((10, 4), -1, dtype=torch.int64, device="cuda"), 200, 50, True)   # nothing to add: zeros
+
+
+def test_rmsprop_kernel_has_tf1_semantics():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    n = 100003
+    g = torch.Generator(device="cuda").manual_seed(2)
+    w = torch.randn(n + 1, device="cuda", generator=g)[:n]
+    w0 = w.clone()
+    ms = torch.ones(n, device="cuda")
+    grad = torch.randn(n, device="cuda", generator=g)
+    ms_ref, w_ref = ms.clone(), w.clone()
+    for it in range(3):
+        A.rmsprop_tf1(w, ms, grad, 1e-4, g_scale=0.5)
+        gs = grad * 0.5
+        ms_ref = 0.9 * ms_ref + 0.1 * gs * gs                     # ms initialised to ones; epsilon inside the sqrt
+        w_ref = w_ref - 1e-4 * gs / torch.sqrt(ms_ref + 1e-10)
+    torch.testing.assert_close(ms, ms_ref, rtol=1e-6, atol=0)
+    torch.testing.assert_close(w, w_ref, rtol=1e-6, atol=1e-7)
+    assert not torch.equal(w, w0)
+
+
+def _twin_runners(torch, n_envs, T, **kw):
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner
+
+    env1 = BatchedMobiEnv(n_envs, nBS=4, nUE=20, grid_n=100, max_step=kw.pop("max_step", 2000))
+    env2 = env1.clone()
+    r1 = A2CRunner(env1, rollout=T, **kw.pop("first", {}))
+    r2 = A2CRunner(env2, rollout=T, **kw.pop("second", {}))
+    return r1, r2
+
+
+def test_fused_update_matches_the_autograd_update():
+    torch = _torch()
+    r1, r2 = _twin_runners(torch, 600, 7, first=dict(fused_update=True, collect_launch="eager"),
+                           second=dict(fused_update=False, collect_launch="eager", update_chunk=1500))
+    assert torch.equal(r1.flat.w, r2.flat.w)
+    for it in range(2):
+        b1, b2 = r1.collect(), r2.collect()
+        for x, y in zip(b1, b2):
+            assert torch.equal(x, y)
+        s1, s2 = r1.update(*b1), r2.update(*b2)
+        np.testing.assert_allclose([s1["a_loss"], s1["c_loss"]], [s2["a_loss"], s2["c_loss"]], rtol=1e-5)
+        for k in r1.flat.gv:
+            g1, g2 = r1.flat.gv[k], r2.flat.gv[k]
+            torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-5 * float(g2.abs().max()) + 1e-12, msg=lambda m: "%s: %s" % (k, m))
+        assert s1["grad_elems"] == s2["grad_elems"] == 20206626
+        torch.testing.assert_close(r1.flat.ms, r2.flat.ms, rtol=1e-4, atol=1e-9)
+        torch.testing.assert_close(r1.flat.w, r2.flat.w, rtol=0, atol=2e-6)        # lr = 1e-4: steps of <= 1e-4 / sqrt(0.9)
+        r2.flat.w.copy_(r1.flat.w)                                                  # keep the twins in lockstep for round 2
+        r2.flat.ms.copy_(r1.flat.ms)
+
+
+def test_graph_captured_rollout_equals_the_eager_rollout():
+    torch = _torch()
+    r1, r2 = _twin_runners(torch, 512, 6, max_step=15, first=dict(collect_launch="graph"), second=dict(collect_launch="eager"))
+    for it in range(4):                                            # crosses done + masked reset (MAXSTEP 15 inside rollout 3)
+        b1, b2 = r1.collect(), r2.collect()
+        for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):
+            assert torch.equal(x, y), "%s differs in rollout %d" % (name, it)
+        assert np.array_equal(r1.env.get_state(), r2.env.get_state())
+        assert torch.equal(r1.idx, r2.idx)
+        r1.update(*b1)
+        r2.update(*b2)
+        assert torch.equal(r1.flat.w, r2.flat.w)                   # deterministic kernels: the twins stay bit-identical
+    assert r1.running_r is not None and r1.running_r == r2.running_r
