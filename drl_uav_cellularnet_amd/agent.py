@@ -276,6 +276,15 @@ class A2CRunner:
         self.act_buf = torch.empty((T, N), dtype=torch.int64, device=self.dev)
         self.rew_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
         self.u_buf = torch.empty((T, N), dtype=torch.float32, device=self.dev)
+        # Forward activations of the rollout, kept for the update: between collect() and update() the weights do not change, so
+        # relu6(first layer) of both trunks, the actor's second layer and its logits for sample (t, n) ARE the update's forward
+        # pass for that sample -- the update only adds the critic's second layer and value head.  (2 GB at 8192 envs x 50 steps.)
+        self._fwd = None
+        if self.dev.type == "cuda":
+            H, NA = HIDDEN, self.net.n_action
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.dev)
+            self._fwd = {"h1a": f(T, N, H), "h1c": f(T, N, H), "h2a": f(T, N, H), "logits": f(T, N, NA)}
+        self._fwd_valid = False
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
         # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
         # every index is -1 = "no row" and the first layer returns its bias.
@@ -315,12 +324,14 @@ class A2CRunner:
         cuda = self.dev.type == "cuda"
         if cuda:
             from . import _agent_capi as A
+        fw = self._fwd
         for t in range(T):
             if cuda:
-                h1 = A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, relu6=True)
-                h2 = torch.addmm(net.a_b2, h1, net.a_w2).clamp_(0.0, 6.0)
-                logits = torch.addmm(net.a_b3, h2, net.a_w3)
-                A.sample_actions(logits, self.u_buf[t], out=self.act_buf[t])
+                A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
+                                  out_c=fw["h1c"][t])
+                torch.addmm(net.a_b2, fw["h1a"][t], net.a_w2, out=fw["h2a"][t]).clamp_(0.0, 6.0)
+                torch.addmm(net.a_b3, fw["h2a"][t], net.a_w3, out=fw["logits"][t])
+                A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
             else:
                 prob = net.actor_only(self.idx_buf[t])
                 self.act_buf[t] = sample_actions(prob, uniforms=self.u_buf[t])
@@ -339,6 +350,7 @@ class A2CRunner:
             self._graph.replay()
         else:
             self._rollout_steps()
+        self._fwd_valid = self._fwd is not None
         self.ep_r += self.rew_buf.sum(dim=0)
         done = env.out["done"].bool()
         boot = self.net.critic_only(self.idx_buf[T]).squeeze(1)                      # :173-176
@@ -398,7 +410,12 @@ class A2CRunner:
             return self._upd
         H, NA, dev = HIDDEN, self.net.n_action, self.dev
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        self._upd = {"M": M, "h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H), "h2c": f(M, H), "dh": f(M, H), "logits": f(M, NA),
+        own = self._fwd is not None and M == self.T * self.env.n_envs      # the rollout's own buffers double as the update's
+        fw = {k: (v.view(M, -1) if own else f(M, v.shape[-1])) for k, v in (self._fwd or {}).items()}
+        if not fw:
+            fw = {"h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H), "logits": f(M, NA)}
+        self._upd = {"M": M, "own": own, "h1a": fw["h1a"], "h1c": fw["h1c"], "h2a": fw["h2a"], "logits": fw["logits"],
+                     "h2c": f(M, H), "dh": f(M, H),
                      "gcat": f(M, 2 * H), "v": f(M), "dv": f(M), "loss": torch.zeros(3, dtype=torch.float64, device=dev),
                      "ws_loss": A.loss_grad_workspace(NA, dev), "ws_relu": A.relu6_bwd_workspace(H, dev),
                      "ws_rows": A.rows_grad_workspace(M, K, 2 * H, self.net.n_state, dev)}
@@ -418,11 +435,14 @@ class A2CRunner:
         idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
         b = self._ensure_update_buffers(M, K)
         gv = fl.gv
-        # forward
-        A.sparse_rows_sum(idx, net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=b["h1a"], out_c=b["h1c"])
-        torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
+        # forward: the actor's activations and both first layers were computed by the rollout itself, with these very weights
+        reuse = b["own"] and self._fwd_valid and idx_buf.data_ptr() == self.idx_buf.data_ptr()
+        if not reuse:
+            A.sparse_rows_sum(idx, net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=b["h1a"], out_c=b["h1c"])
+            torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
+            torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
+        self._fwd_valid = False                                        # the backward pass below overwrites logits and h2a
         torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
-        torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
         A.rowdot(b["h2c"], net.c_w3, net.c_b3, b["v"])
         # loss and its gradient w.r.t. logits / v (logits are overwritten); d a_b3, d c_b3
         A.a2c_loss_grad(b["logits"], b["v"], target, act, self.beta, b["dv"], gv["a_b3"], b["loss"], b["ws_loss"])
@@ -451,7 +471,8 @@ class A2CRunner:
         A.rmsprop_tf1(fl.w[ae:], fl.ms[ae:], fl.g[ae:], self.lr_c, g_scale=g_scale)
         loss = b["loss"].cpu()                                        # (synchronises)
         self.stats = {"a_loss": float(loss[0]), "c_loss": float(loss[1]), "mean_reward": float(rew_buf.mean()),
-                      "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1)}
+                      "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1),
+                      "forward_reused": bool(reuse)}
         return self.stats
 
     def update_reference(self, idx_buf, act_buf, rew_buf, boot):

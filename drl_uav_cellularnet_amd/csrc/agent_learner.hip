@@ -204,14 +204,34 @@ __global__ __launch_bounds__(256) void a2c_loss_grad_kernel(float *__restrict__ 
     if (lane == 0) { loss_partial[wave * 3] = la; loss_partial[wave * 3 + 1] = lc; loss_partial[wave * 3 + 2] = sdv; }
 }
 
-// out[c] = sum_w partial[w][c], w ascending (deterministic).  One thread per column.
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, long long n_part, int C,
-                                                            float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] = sum_w partial[w][c] in a FIXED order (deterministic): a block owns 64 columns; its 16 slab-threads per column each add
+// a contiguous slab of the partial rows in ascending order (64 consecutive floats per load instruction: coalesced), then the
+// 16 slab sums are added in slab order.  (The first version, one thread per column over all 4096 partial rows, took 0.99 ms per
+// call, 5.9 ms per update: profiles/r02b_a2c_profile_fused_first.txt.)
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ partial, long long n_part, int C,
+                                                             float *__restrict__ out) {
+    __shared__ float slab_sum[16][64];
+    const int cl = threadIdx.x & 63, slab = threadIdx.x >> 6;          // 16 slabs x 64 columns
+    const int c = blockIdx.x * 64 + cl;
+    const long long per = (n_part + 15) / 16;
+    const long long w0 = slab * per, w1 = (w0 + per < n_part) ? w0 + per : n_part;
     float s = 0.f;
-    for (long long w = 0; w < n_part; ++w) s += partial[w * C + c];
-    out[c] = s;
+    if (c < C) {
+        long long w = w0;
+        for (; w + 4 <= w1; w += 4) {                                   // four independent loads in flight, added in order
+            const float a0 = partial[w * C + c], a1 = partial[(w + 1) * C + c], a2 = partial[(w + 2) * C + c], a3 = partial[(w + 3) * C + c];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; w < w1; ++w) s += partial[w * C + c];
+    }
+    slab_sum[slab][cl] = s;
+    __syncthreads();
+    if (slab == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += slab_sum[k][cl];
+        out[c] = t;
+    }
 }
 __global__ void loss_reduce_kernel(const double *__restrict__ partial, long long n_part, double inv_m, double *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -540,7 +560,7 @@ extern "C" int uavagent_a2c_loss_grad(float *logits_inout, const float *v, const
     }
 #undef UAVAGENT_LOSS
     if (int rc = launch_ok("a2c_loss_grad")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_actions + 255) / 256), dim3(256), 0, s, colp, waves, (int)n_actions, dbias_out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_actions + 63) / 64), dim3(1024), 0, s, colp, waves, (int)n_actions, dbias_out);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, s, lossp, waves, 1.0 / (double)m_rows, loss_out);
     return launch_ok("a2c_loss_grad reduce");
 }
@@ -561,8 +581,8 @@ extern "C" int uavagent_relu6_bwd(const float *dy, const float *y, const float *
     if (outer) hipLaunchKernelGGL((relu6_bwd_kernel<true>), dim3(kReluBlocks), dim3(256), 0, s, dy, y, dv, w3, (long long)m_rows, (int)(n_cols / 4), dx_out, (long long)ldx, p0, p1);
     else hipLaunchKernelGGL((relu6_bwd_kernel<false>), dim3(kReluBlocks), dim3(256), 0, s, dy, y, dv, w3, (long long)m_rows, (int)(n_cols / 4), dx_out, (long long)ldx, p0, p1);
     if (int rc = launch_ok("relu6_bwd")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p0, waves, (int)n_cols, dbias_out);
-    if (outer) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, p1, waves, (int)n_cols, dw3_out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_cols + 63) / 64), dim3(1024), 0, s, p0, waves, (int)n_cols, dbias_out);
+    if (outer) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_cols + 63) / 64), dim3(1024), 0, s, p1, waves, (int)n_cols, dw3_out);
     return launch_ok("relu6_bwd reduce");
 }
 

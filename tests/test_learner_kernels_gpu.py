@@ -214,13 +214,17 @@ def test_fused_update_matches_the_autograd_update():
         b1, b2 = r1.collect(), r2.collect()
         for x, y in zip(b1, b2):
             assert torch.equal(x, y)
+        if it == 1:
+            r1._fwd_valid = False          # round 2: the update recomputes its forward pass instead of reusing the rollout's
         s1, s2 = r1.update(*b1), r2.update(*b2)
+        assert s1["forward_reused"] == (it == 0)
         np.testing.assert_allclose([s1["a_loss"], s1["c_loss"]], [s2["a_loss"], s2["c_loss"]], rtol=1e-5)
         for k in r1.flat.gv:
             g1, g2 = r1.flat.gv[k], r2.flat.gv[k]
             torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-5 * float(g2.abs().max()) + 1e-12, msg=lambda m: "%s: %s" % (k, m))
         assert s1["grad_elems"] == s2["grad_elems"] == 20206626
-        torch.testing.assert_close(r1.flat.ms, r2.flat.ms, rtol=1e-4, atol=1e-9)
+        for k in r1.flat.gv:              # (views only: the fused step also decays the alignment padding's accumulator, harmlessly)
+            torch.testing.assert_close(r1._ms_view(k), r2._ms_view(k), rtol=1e-4, atol=1e-9)
         torch.testing.assert_close(r1.flat.w, r2.flat.w, rtol=0, atol=2e-6)        # lr = 1e-4: steps of <= 1e-4 / sqrt(0.9)
         r2.flat.w.copy_(r1.flat.w)                                                  # keep the twins in lockstep for round 2
         r2.flat.ms.copy_(r1.flat.ms)
