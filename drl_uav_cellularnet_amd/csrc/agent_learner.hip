@@ -233,11 +233,16 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__rest
         out[c] = t;
     }
 }
-__global__ void loss_reduce_kernel(const double *__restrict__ partial, long long n_part, double inv_m, double *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wavefront: lane l adds the partials w = l, l + 64, ... in ascending order, then a fixed shuffle tree (deterministic).
+// (A single thread over all 4096 partials took 0.53 ms: profiles/r02b_a2c_profile_fused_second.txt.)
+__global__ __launch_bounds__(64) void loss_reduce_kernel(const double *__restrict__ partial, long long n_part, double inv_m,
+                                                         double *__restrict__ out) {
+    const int lane = threadIdx.x;
     double a = 0.0, c = 0.0, d = 0.0;
-    for (long long w = 0; w < n_part; ++w) { a += partial[w * 3]; c += partial[w * 3 + 1]; d += partial[w * 3 + 2]; }
-    out[0] = a * inv_m; out[1] = c * inv_m; out[2] = d;     // mean actor loss, mean critic loss, sum of dv (= d loss / d b3c)
+    for (long long w = lane; w < n_part; w += 64) { a += partial[w * 3]; c += partial[w * 3 + 1]; d += partial[w * 3 + 2]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); c += __shfl_xor(c, off, 64); d += __shfl_xor(d, off, 64); }
+    if (lane == 0) { out[0] = a * inv_m; out[1] = c * inv_m; out[2] = d; }   // mean actor loss, mean critic loss, sum of dv (= d loss / d b3c)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
