@@ -312,8 +312,10 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
         if (h->packed) {
             if (fast) hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, true, false>), dim3(grid), blk, 0, s, PK_ARGS);
             else hipLaunchKernelGGL((env_kernel_packed<4, MODE_WARMUP, true, false, false>), dim3(grid), blk, 0, s, PK_ARGS);
+        } else if (fast) {
+            hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true, true>), dim3(grid), blk, 0, s, p);
         } else {
-            hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true>), dim3(grid), blk, 0, s, p);
+            hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, p);
         }
         HIP_TRY(hipGetLastError());
         return UAVENV_OK;
@@ -337,8 +339,13 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
         if (h->packed) {                                                                                         \
             if (h->plc) UAVENV_LAUNCH_PK(BT_, true); else UAVENV_LAUNCH_PK(BT_, false);                          \
         } else if (!MANY) {                                                                                      \
-            if (h->plc) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true>), dim3(grid), blk, 0, s, p);      \
-            else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false>), dim3(grid), blk, 0, s, p);            \
+            if (h->plc) {                                                                                        \
+                if (fast) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true, true>), dim3(grid), blk, 0, s, p);   \
+                else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true, false>), dim3(grid), blk, 0, s, p);       \
+            } else {                                                                                             \
+                if (fast) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false, true>), dim3(grid), blk, 0, s, p);  \
+                else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false, false>), dim3(grid), blk, 0, s, p);      \
+            }                                                                                                    \
         }                                                                                                        \
     } while (0)
     switch (h->bt) {

@@ -907,12 +907,72 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
 
 // ================================================================================================
 // Multi-pass env kernel: U > 64 (or a slot too narrow for its owner lanes): one env per wavefront, walkers
-// in passes of 64 lanes.  Same helpers, wave-uniform env scalars.
+// in passes of 64 lanes.  Same helpers, wave-uniform env scalars.  BASELINE config 5 (16 UAV x 200 UE) runs here.
+//
+// What round 2 changed, each from the r02a profile of <16, 2, true> at 8192 envs (214 us, 12 053 VALU instructions per wavefront,
+// 204 VGPRs, VALU-issue bound: profiles/r02a_pmc_and_trace_digest.txt):
+//   FAST        no injected draws, all nine outputs, B == BT: the per-UAV `b < B` guards and pointer tests fold away;
+//   PRE         the two Philox calls that give a walker its new heading ARE its fading calls 0 and 1 (same counters):
+//               made once instead of twice (the packed kernel has always done this);
+//   UAV cells   read from their LDS row (one broadcast ds_read_b64 per UAV) when BT >= 16 instead of 2 x BT registers;
+//   item tail   the last U mod 64 walkers (8 of 200) used to cost a whole pass of HB = B/2 fading iterations at 12 % lane
+//               use; they now take ONE iteration with a lane per (walker, UAV pair) and 3-step butterfly reductions for
+//               the argmax / interference sums (tail_items(): when HB is a power of two and (U mod 64) * HB <= 64);
+//   loads       env record, outage words and group ids are fetched before the first pass, not inside it.
 // ================================================================================================
-template <int BT, int MODE, bool PLC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(const KParams p) {
+// Two N(mean, sd) shadowing draws from one Philox call (Box-Muller), exactly as rx_power() forms them.
+__device__ __forceinline__ void fading_pair(const HotConst &H, const LeanCoef &C, const U4 &q, double &f0, double &f1) {
+    const double u0 = u53(q.x, q.y);
+    const double t = -2.0 * lm_logc(1.0 - u0, C);
+    const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;
+    double sa, ca;
+    lm_sincospi((double)q.z * (1.0 / 2147483648.0), C, &sa, &ca);
+    f0 = H.sh_mean + H.sh_sd * (r * ca);
+    f1 = H.sh_mean + H.sh_sd * (r * sa);
+}
+// Received power of one UAV at one walker: the arithmetic of rx_power()'s inner block (channel.py:220-257).
+template <bool PLC>
+__device__ __forceinline__ double rx_gain(const HotConst &H, const LeanCoef &C, int ix, int iy, int bx, int by, double f) {
+    const double fx = H.gw * (double)(ix - bx);
+    const double fy = H.gw * (double)(iy - by);
+    const double d2 = fx * fx + fy * fy;
+    double g;
+    if (PLC) {
+        const double rinv = lm_rsqrt(d2);
+        g = H.k_pl * lm_exp2(H.c_exp * f, C) * (rinv * rinv * rinv);
+    } else {
+        g = H.k_pl * lm_exp2(H.c_exp * f - H.pl_exp_ln * lm_logc(d2, C), C);
+    }
+    if (!(d2 > H.pl_dis2)) g = H.k_0 * lm_exp2(H.c_exp * f, C);
+    return g;
+}
+// Sum / first-maximum over the G consecutive lanes of an aligned group (G a power of two <= 64): xor butterflies, every lane
+// of the group ends with the same value.
+__device__ __forceinline__ double group_sum(double v, int G) {
+    for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void group_argmax(double &v, int &i, int G) {     // ties: the LOWER index wins (np.argmax)
+    for (int off = 1; off < G; off <<= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(i, off, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+// Item layout for the tail walkers?  -> lanes per walker (HB) or 0.
+__device__ __forceinline__ int tail_items(int U, int B) {
+    const int R = U & 63, HB = (B + 1) >> 1;
+    return (R > 0 && (HB & (HB - 1)) == 0 && HB >= 2 && R * HB <= 64) ? HB : 0;
+}
+
+#ifndef UAVENV_MP_WAVES
+#define UAVENV_MP_WAVES 3     // occupancy the register allocator must allow (waves per SIMD): 3 -> <= 168 VGPRs, 4 -> <= 128
+#endif
+template <int BT, int MODE, bool PLC, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(UAVENV_MP_WAVES)))
+void env_kernel_multipass(const KParams p) {
     const StatePtrs st = state_from_params(p);
-    constexpr bool FAST = false;  // U > 64: per-wave work is large, the checked path is kept
+    constexpr bool PRE = FAST && has_mobility(MODE);
     __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
     kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
@@ -920,20 +980,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
     const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
     if (e >= p.N) return;
     if (is_reset(MODE)) { if (p.mask != nullptr && p.mask[e] == 0) return; }
-    const LeanCoef C = lm_make_coef<false>();   // polynomial coefficients, pinned in VGPRs once per kernel (lean_math.h)
-    const HotConst H = make_hot<false>(p);      // hot kernarg doubles, pinned in VGPRs (frees ~30 SGPRs)
+    // Constants stay unpinned (SGPRs / literals).  Measured on one box at 8192 envs of 16 x 200 (profiles/r02c_*): pinning them
+    // in VGPRs as the packed kernel's PIN variant does: -12 % instructions but 187 VGPRs = 2 wavefronts per SIMD, 151.5 vs
+    // 154.5 us; serving the 38 polynomial coefficients of the fading loop from LDS (one broadcast ds_read per use, -11 % VALU in
+    // that loop, 167 VGPRs): 154.0 vs 154.1 us -- the LDS round trips it adds to each wave's dependency chain cost what the
+    // moves did; forcing 4 wavefronts per SIMD (128 VGPRs, 28 scratch spills): 152.9 us.  None is worth its complexity.
+    const LeanCoef C = lm_make_coef<false>();
+    const HotConst H = make_hot<false>(p);
 
-    const int U = p.U, B = p.B, Gr = p.Gr;
+    const int U = p.U, B = uav_count<BT, FAST>(p.B), Gr = p.Gr;
+    const int HB = (B + 1) >> 1;
     const double MAXC = H.maxc;
-    const int n_pass = (U + 63) >> 6;
+    const int n_full = U >> 6, R = U & 63;
+    const int n_pass = n_full + (R ? 1 : 0);
+    const int IT = (MODE == MODE_WARMUP) ? 0 : tail_items(U, B);        // lanes per tail walker in the item layout, or 0
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
+    int *bs_row = s_bs[wave];
 
+    // ---- loads that do not depend on the pass --------------------------------------------------------------------
+    const EnvRec erec = st.env[e];
+    unsigned long long prev_w = 0ull;                                     // lane w < W64 holds outage word w of the last update
+    if (is_step(MODE) && lane < p.W64) prev_w = st.out_bits[e * p.W64 + lane];
+    const bool gown = lane < Gr;
+    double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
+    if (has_mobility(MODE) && gown) {
+        const GrpRec g = st.grp[e * Gr + lane];
+        ogx = g.x; ogy = g.y; ogfl = g.fl; ogv = g.v; ogc = g.c; ogs = g.s;
+    }
+
+    // ---- UAV move: Decimal_to_Base_N + BS_move, cooperative (one UAV per lane), cells to LDS -------------------------
     if (MODE != MODE_WARMUP) {
         const bool bown = lane < B;
         int bx = 0, by = 0, dig = 0;
         if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * lane]; by = p.bs_init[2 * lane + 1]; }
-            else { bx = st.bs_xy[(e * B + lane) * 2]; by = st.bs_xy[(e * B + lane) * 2 + 1]; }
+            else { const int2 q = reinterpret_cast<const int2 *>(st.bs_xy)[e * B + lane]; bx = q.x; by = q.y; }
         }
         if (is_step(MODE)) {
             if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane]);
@@ -948,50 +1029,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
             }
         }
         if (bown) {
-            st.bs_xy[(e * B + lane) * 2] = bx; st.bs_xy[(e * B + lane) * 2 + 1] = by;
-            s_bs[wave][2 * lane] = bx; s_bs[wave][2 * lane + 1] = by;
-            if (p.out.bs_xy) { p.out.bs_xy[(e * B + lane) * 2] = bx; p.out.bs_xy[(e * B + lane) * 2 + 1] = by; }
+            reinterpret_cast<int2 *>(st.bs_xy)[e * B + lane] = int2{bx, by};
+            bs_row[2 * lane] = bx; bs_row[2 * lane + 1] = by;
+            if (UAV_OUT(p.out.bs_xy)) reinterpret_cast<int2 *>(p.out.bs_xy)[e * B + lane] = int2{bx, by};
         }
         __builtin_amdgcn_wave_barrier();
     }
-    int bsx[BT], bsy[BT];                  // UAV cells of this env, LDS row -> registers once (rx_power reads them)
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-        bsx[b] = 0; bsy[b] = 0;
-        if (MODE != MODE_WARMUP && b < B) { bsx[b] = s_bs[wave][2 * b]; bsy[b] = s_bs[wave][2 * b + 1]; }
-    }
-
-    const EnvRec erec = st.env[e];
     int agg = erec.agg, deagg = erec.deagg;
     uint32_t tick = erec.tick;
     const int depth = erec.fifo_depth, step_n = erec.step_n;
-    const bool gown = lane < Gr;
-
     double sum_cur = 0.0;
     int n_outage = 0;
 
     for (int it = 0; it < n_ticks; ++it) {
-        double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
         const bool aggregating = agg != 0;
-        if (has_mobility(MODE)) {
-            if (gown) {
-                const GrpRec g = st.grp[e * Gr + lane];
-                ogx = g.x; ogy = g.y; ogfl = g.fl; ogv = g.v; ogc = g.c; ogs = g.s;
-                ogx = ogx + ogv * ogc;
-                ogy = ogy + ogv * ogs;
-            }
+        if (has_mobility(MODE) && gown) {                                 // ue_mobility.py:458-459
+            ogx = ogx + ogv * ogc;
+            ogy = ogy + ogv * ogs;
         }
         uint32_t touched[4] = {0u, 0u, 0u, 0u};
 
         for (int pass = 0; pass < n_pass; ++pass) {
-            const int u = pass * 64 + lane;
+            // Lane -> walker.  Full passes and the plain tail: one walker per lane, all HB fading pairs in that lane.
+            // Item tail: IT lanes per walker, lane (ul, hb) does fading pair hb of walker 64 * n_full + ul.
+            const bool item = (IT != 0) && (pass == n_full);
+            const int ul = item ? lane / (IT ? IT : 1) : lane;
+            const int hb = item ? lane - ul * IT : 0;
+            const int u = pass * 64 + ul;
             const bool act = u < U;
+            const bool owner = act && (!item || hb == 0);                  // the lane that stores the walker's results
             const long long iu = e * U + (act ? u : 0);
             int ix = 0, iy = 0;
-            UeAux aux = st.ue_aux[iu];                            // inactive lanes read walker 0 of the env and store nothing
+            UeAux aux = st.ue_aux[iu];                                    // inactive lanes read walker 0 of the env and store nothing
+            U4 h0 = {0u, 0u, 0u, 0u}, h1 = {0u, 0u, 0u, 0u};
             if (has_mobility(MODE)) {
-                int gid = 0;
-                for (int g = 1; g < Gr; ++g) gid += (u >= p.group_start[g]) ? 1 : 0;
+                const int gid = p.gid_of_u[act ? u : 0];                   // table: RPGM group of walker u (ue_mobility.py:417-426)
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
                 const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
                 double x = 0, y = 0, hu = aux.hu;
@@ -1007,68 +1079,118 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_multipass(cons
                             if (__ballot(mine && c[k]) != 0ull) touched[k] |= 1u << g;
                     }
                 }
-                if (p.inj_theta) { if (act) hu = p.inj_theta[iu]; }
+                if (UAV_INJ(p.inj_theta)) { if (act) hu = p.inj_theta[iu]; }
                 else {
-                    const int HB = (B + 1) >> 1;
-                    const U4 h0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
-                    const U4 h1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : h0;
+                    h0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
+                    h1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : h0;
                     hu = heading_from(h0, h1, HB);
                 }
                 ix = (int)x; iy = (int)y;
                 aux.hu = hu;
-                if (act) st.ue_pos[iu] = UePos{x, y};
+                if (owner) st.ue_pos[iu] = UePos{x, y};
             } else if (act) {
                 ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
             }
             aux.ix = (int16_t)ix; aux.iy = (int16_t)iy;
-            if (MODE == MODE_WARMUP) { if (act) st.ue_aux[iu] = aux; continue; }
-            if (act && p.out.ue_xy) { p.out.ue_xy[2 * iu] = (int16_t)ix; p.out.ue_xy[2 * iu + 1] = (int16_t)iy; }
+            if (MODE == MODE_WARMUP) { if (owner) st.ue_aux[iu] = aux; continue; }
+            if (owner && UAV_OUT(p.out.ue_xy)) reinterpret_cast<int *>(p.out.ue_xy)[iu] = (int)(uint16_t)ix | ((int)(uint16_t)iy << 16);
 
-            double pg[BT];
-            { const U4 z = {0u, 0u, 0u, 0u}; rx_power<BT, PLC, FAST, false>(p, H, C, e, tick, u, act, iu, ix, iy, bsx, bsy, z, z, pg); }
-            double best_pg;
-            const int best = argmax_pg<BT, FAST>(p, pg, best_pg);
-            const double bestS = sinr_db_px<BT, FAST>(p, H, C, pg, best, best_pg);
-            if (is_reset(MODE)) {
-                const unsigned long long ob = __ballot(act && (bestS <= H.out_thr));
-                if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
-                if (act) {
-                    aux.serving = (int8_t)best; aux.r0 = (int8_t)best;
-                    st.ue_aux[iu] = aux;
-                    if (p.out.serving) p.out.serving[iu] = (int8_t)best;
-                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)bestS;
-                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = bestS;
+            // ---- received powers, best UAV, the two SINR values -------------------------------------------------
+            int best, serving = aux.serving;
+            double bestS, cur = 0.0;
+            if (!item) {
+                // A ROLLED loop over the HB fading pairs with running reductions instead of a pg[BT] array: the unrolled form
+                // needed 204-206 VGPRs (2 wavefronts per SIMD) and 83-118 SGPR spills at BT = 16.  What SINR needs from the B
+                // powers: the first maximum and the sum of the OTHERS (a displaced maximum joins that sum when it is displaced,
+                // so nothing is ever subtracted), and for the serving UAV its power and the sum of the others in index order.
+                double bp = 0.0, others_b = 0.0, ps = 0.0, others_s = 0.0;
+                best = 0;
+#pragma unroll 1
+                for (int k = 0; k < HB; ++k) {
+                    const int b0 = 2 * k, b1 = 2 * k + 1;
+                    double f0 = 0.0, f1 = 0.0;
+                    if (UAV_INJ(p.inj_fading)) {
+                        if (act) { f0 = p.inj_fading[iu * B + b0]; if (b1 < B) f1 = p.inj_fading[iu * B + b1]; }
+                    } else {
+                        U4 q = (k == 0) ? h0 : h1;                              // PRE: this walker's calls 0 / 1 exist already
+                        if (!PRE || k >= 2) q = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + k), DOM_FADING);   // (k is wave-uniform)
+                        fading_pair(H, C, q, f0, f1);
+                    }
+                    const double g0 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
+                    if (k == 0) { bp = g0; best = 0; }
+                    else if (g0 > bp) { others_b += bp; bp = g0; best = b0; }
+                    else others_b += g0;
+                    others_s += (b0 == serving) ? 0.0 : g0;
+                    ps = (b0 == serving) ? g0 : ps;
+                    if (b1 < B) {
+                        const double g1 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b1], bs_row[2 * b1 + 1], f1);
+                        if (g1 > bp) { others_b += bp; bp = g1; best = b1; }
+                        else others_b += g1;
+                        others_s += (b1 == serving) ? 0.0 : g1;
+                        ps = (b1 == serving) ? g1 : ps;
+                    }
                 }
-                sum_cur += wave_sum(act ? bestS : 0.0);
+                bestS = H.db_per_ln * lm_logc(lm_div(bp, H.noise + others_b), C);           // channel.py:259-268
+                if (!is_reset(MODE)) cur = H.db_per_ln * lm_logc(lm_div(ps, H.noise + others_s), C);
             } else {
-                int serving = aux.serving, r0 = aux.r0, r1 = aux.r1, r2 = aux.r2;
-                const double cur = sinr_db<BT, FAST>(p, H, C, pg, serving);
-                fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
-                const unsigned long long ob = __ballot(act && (cur <= H.out_thr));
-                const unsigned long long prev = st.out_bits[e * p.W64 + pass];
-                n_outage += __popcll(ob & ~prev);
-                if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
-                if (act) {
-                    aux.serving = (int8_t)serving; aux.r0 = (int8_t)r0; aux.r1 = (int8_t)r1; aux.r2 = (int8_t)r2;
-                    st.ue_aux[iu] = aux;
-                    if (p.out.serving) p.out.serving[iu] = (int8_t)serving;
-                    if (p.out.cur_sinr) p.out.cur_sinr[iu] = (float)cur;
-                    if (p.out.cur_sinr_f64) p.out.cur_sinr_f64[iu] = cur;
+                // one fading pair per lane; group = the IT lanes of one walker
+                const int b0 = 2 * hb, b1 = 2 * hb + 1;
+                double f0 = 0.0, f1 = 0.0;
+                if (UAV_INJ(p.inj_fading)) {
+                    if (act) { f0 = p.inj_fading[iu * B + b0]; if (b1 < B) f1 = p.inj_fading[iu * B + b1]; }
+                } else {
+                    const U4 q = (PRE && hb == 0) ? h0 : ((PRE && hb == 1) ? h1 :
+                                 philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + hb), DOM_FADING));
+                    fading_pair(H, C, q, f0, f1);
                 }
-                sum_cur += wave_sum(act ? cur : 0.0);
+                const double g0 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
+                const double g1 = (b1 < B) ? rx_gain<PLC>(H, C, ix, iy, bs_row[2 * (b1 < B ? b1 : b0)], bs_row[2 * (b1 < B ? b1 : b0) + 1], f1) : 0.0;
+                double bp = g0; best = b0;
+                if (b1 < B && g1 > g0) { bp = g1; best = b1; }             // first maximum inside the pair, then across the group
+                group_argmax(bp, best, IT);
+                // interference = the OTHER UAVs (never total - self); the group sum adds them in butterfly order
+                const double ib = group_sum(((b0 != best) ? g0 : 0.0) + ((b1 != best && b1 < B) ? g1 : 0.0), IT);
+                bestS = H.db_per_ln * lm_logc(lm_div(bp, H.noise + ib), C);
+                if (!is_reset(MODE)) {
+                    const double is = group_sum(((b0 != serving) ? g0 : 0.0) + ((b1 != serving && b1 < B) ? g1 : 0.0), IT);
+                    const double ps = group_sum(((b0 == serving) ? g0 : 0.0) + ((b1 == serving && b1 < B) ? g1 : 0.0), IT);
+                    cur = H.db_per_ln * lm_logc(lm_div(ps, H.noise + is), C);
+                }
             }
+
+            // ---- handover, outage, stores ------------------------------------------------------------------------
+            int r0 = aux.r0, r1 = aux.r1, r2 = aux.r2;
+            if (is_reset(MODE)) { cur = bestS; serving = best; r0 = best; }   // LTEChannel.reset / GetBestDlBS (channel.py:113-124)
+            else fifo_handover(H, depth, best, bestS, cur, serving, r0, r1, r2);
+            unsigned long long ob = __ballot(owner && (cur <= H.out_thr));     // :116 / :170
+            if (item) {                                                        // owner lanes sit IT apart: compact to bit = walker
+                unsigned long long cb = 0ull;
+                for (int k = 0; k < R; ++k) cb |= ((ob >> (k * IT)) & 1ull) << k;
+                ob = cb;
+            }
+            if (is_step(MODE)) {
+                const unsigned long long prev = __shfl(prev_w, pass, 64);
+                n_outage += __popcll(ob & ~prev);                              // :171-174 newly outaged
+            }
+            if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
+            if (owner) {
+                aux.serving = (int8_t)serving; aux.r0 = (int8_t)r0; aux.r1 = (int8_t)r1; aux.r2 = (int8_t)r2;
+                st.ue_aux[iu] = aux;
+                if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
+                if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
+                if (UAV_OUT64(p.out.cur_sinr_f64)) p.out.cur_sinr_f64[iu] = cur;
+            }
+            sum_cur += wave_sum(owner ? cur : 0.0);
         }  // passes
 
         if (has_mobility(MODE)) {
-            if (gown) {
-                group_finish<FAST>(p, C, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
-                st.grp[e * Gr + lane] = GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs};
-            }
+            if (gown) group_finish<FAST>(p, C, e, lane, tick, touched, MAXC, ogfl, ogv, ogc, ogs);
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }
             else { deagg -= 1; if (deagg == 0) agg = p.agg_len; }
         }
         tick += 1u;
     }
+    if (has_mobility(MODE) && gown) st.grp[e * Gr + lane] = GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs};
     if (lane == 0) env_finish<MODE, FAST>(p, p.out, st, (uint32_t)e, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
 }
 
