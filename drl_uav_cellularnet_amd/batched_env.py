@@ -34,6 +34,9 @@ _OUT_SPECS = {
     "reward_f64": (torch.float64, lambda N, U, B: (N,)),
 }
 
+_NP_DTYPES = {torch.float32: np.float32, torch.float64: np.float64, torch.uint8: np.uint8, torch.int8: np.int8,
+              torch.int16: np.int16, torch.int32: np.int32}
+
 # Record formats of the state blob (include/uavenv.h, csrc/state_layout.h), little-endian, no implicit padding.
 _REC_DTYPES = {
     "ue_pos": np.dtype([("x", "<f8"), ("y", "<f8")]),
@@ -69,12 +72,23 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_create(C.byref(self.cfg), self.n_envs, self.device.index, self.seed,
                                             self.env_id_base, C.byref(self._h)))
         N, U, B = self.n_envs, self.nUE, self.nBS
+        # All output tensors are views of ONE device arena (each on a 256-byte boundary): out_host() then brings every output
+        # to the host with a single device-to-host copy (the N = 1 shim reads them all after each step).
         self.out = {}
         self._out_struct = _capi.UavEnvOut()
+        specs, off = [], 0
         for name, (dt, shp) in _OUT_SPECS.items():
             if name.endswith("_f64") and not f64_outputs:
                 continue
-            t = torch.zeros(shp(N, U, B), dtype=dt, device=self.device)
+            shape = shp(N, U, B)
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            specs.append((name, dt, shape, off, nbytes))
+            off = (off + nbytes + 255) // 256 * 256
+        self._arena = torch.zeros(max(off, 256), dtype=torch.uint8, device=self.device)
+        self._arena_specs = specs
+        self._host_arena = None
+        for name, dt, shape, o, nbytes in specs:
+            t = self._arena[o:o + nbytes].view(dt).view(shape)
             self.out[name] = t
             setattr(self._out_struct, name + "_dev", t.data_ptr())
         self._out_ref = C.byref(self._out_struct)
@@ -273,6 +287,18 @@ class BatchedMobiEnv:
         if a.numel() != self.n_envs:
             raise ValueError("actions must have n_envs elements")
         return a
+
+    def out_host(self):
+        """Every output of the last reset / step as NumPy views of one pinned host buffer: one D2H copy, one synchronisation.
+        The views are overwritten by the next call."""
+        if self._host_arena is None:
+            self._host_arena = torch.empty(self._arena.shape, dtype=torch.uint8, pin_memory=True)
+            self._host_np = self._host_arena.numpy()
+            self._host_views = {name: self._host_np[o:o + nbytes].view(_NP_DTYPES[dt]).reshape(shape)
+                                for name, dt, shape, o, nbytes in self._arena_specs}
+        self._host_arena.copy_(self._arena, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._host_views
 
     def observation(self):
         """Compact observation: the ~(U+B) non-zero cells of the reference's state tensor."""

@@ -338,13 +338,13 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     do {                                                                                                         \
         if (h->packed) {                                                                                         \
             if (h->plc) UAVENV_LAUNCH_PK(BT_, true); else UAVENV_LAUNCH_PK(BT_, false);                          \
-        } else if (!MANY) {                                                                                      \
+        } else if (!MANY) {   /* the checked multi-pass variant reads B at run time: one instantiation serves every BT */ \
             if (h->plc) {                                                                                        \
                 if (fast) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true, true>), dim3(grid), blk, 0, s, p);   \
-                else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, true, false>), dim3(grid), blk, 0, s, p);       \
+                else hipLaunchKernelGGL((env_kernel_multipass<4, M, true, false>), dim3(grid), blk, 0, s, p);         \
             } else {                                                                                             \
                 if (fast) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false, true>), dim3(grid), blk, 0, s, p);  \
-                else hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false, false>), dim3(grid), blk, 0, s, p);      \
+                else hipLaunchKernelGGL((env_kernel_multipass<4, M, false, false>), dim3(grid), blk, 0, s, p);        \
             }                                                                                                    \
         }                                                                                                        \
     } while (0)

@@ -125,25 +125,43 @@ class MobiEnvironment:
         return np.ascontiguousarray(self.ueLoc_trace[i][:self.nUE, :2].astype(np.int16))[None]
 
     def _dense(self):
-        return self._env.dense_obs()[0].double().cpu().numpy()
+        """env.state from the compact cells, on the host: plane 0 counts the UAV cells (GetGridMap, ue_mobility.py:173-188),
+        plane 1 + b the UEs served by UAV b (GetCurrentAssociationMap, channel.py:387-409).  The device-side dense tensor
+        (uavenv_obs_dense) holds the same numbers (tests/test_shim_dropin.py); building the nBS + nUE cells here avoids a
+        400 KB device-to-host copy per step."""
+        G = self.grid_n
+        st = np.zeros((self.nBS + 1, G, G))
+        np.add.at(st[0], (self.bsLoc[:, 0], self.bsLoc[:, 1]), 1.0)
+        ok = (self.ueLoc >= 0).all(axis=1) & (self.ueLoc < G).all(axis=1)     # a walker on x == G has no cell (SURVEY Q9)
+        np.add.at(st, (1 + self.channel.current_BS[ok], self.ueLoc[ok, 0], self.ueLoc[ok, 1]), 1.0)
+        return st
 
     def _pull(self, refresh_state=True):
-        import torch
-
-        torch.cuda.synchronize(self._env.device)
-        o = self._env.out
-        self.ueLoc = o["ue_xy"][0].cpu().numpy().astype(np.int64)
-        xy = o["bs_xy"][0].cpu().numpy().astype(np.int64)
+        h = self._env.out_host()                                        # ONE device-to-host copy + synchronisation
+        self._h = h
+        self.ueLoc = h["ue_xy"][0].astype(np.int64)
+        xy = h["bs_xy"][0].astype(np.int64)
         self.bsLoc = np.concatenate([xy, np.full((self.nBS, 1), self.bs_h, dtype=np.int64)], axis=1)
-        self.channel.current_BS = o["serving"][0].cpu().numpy().astype(np.int64)
-        self.channel.current_BS_sinr = o["cur_sinr_f64"][0].cpu().numpy().copy()
-        self.step_n = int(o["step_n"][0])
+        self.channel.current_BS = h["serving"][0].astype(np.int64)
+        self.channel.current_BS_sinr = h["cur_sinr_f64"][0].copy()
+        self.step_n = int(h["step_n"][0])
         if refresh_state:
             self.state = self._dense()                                  # mobile_env.py:139-140 / 169-170
 
     @staticmethod
     def _action(action):
         return int(np.asarray(action).ravel()[0])                     # int, NumPy int or shape-(1,) array (main_test.py:73-75)
+
+    def _action_dev(self, a):
+        """The action as a device tensor through a pinned staging word (no per-step tensor construction)."""
+        import torch
+
+        if getattr(self, "_act_host", None) is None:
+            self._act_host = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+            self._act_dev = torch.zeros(1, dtype=torch.int64, device=self._env.device)
+        self._act_host[0] = a
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        return self._act_dev
 
     def _digits(self, a):
         d = np.zeros(self.nBS)
@@ -170,7 +188,7 @@ class MobiEnvironment:
         import torch
 
         self._pull()
-        o = self._env.out
+        o = self._h
         mean_sinr = float(o["mean_sinr_f64"][0])
         n_out = int(o["n_out"][0])
         r_dissect = [mean_sinr / 20, -1.0 * n_out / self.nUE]          # mobile_env.py:163-167
@@ -185,10 +203,9 @@ class MobiEnvironment:
 
         a = self._action(action)
         if self.mobility_model == "group":
-            self._env.step(torch.tensor([a], dtype=torch.int64, device=self._env.device), **self._draws("step"))
+            self._env.step(self._action_dev(a), **self._draws("step"))
         else:  # the reference's step() would call next(self.mm) on an empty list here; replay the trace instead
-            self._env.step_trace(torch.tensor([a], dtype=torch.int64, device=self._env.device),
-                                 self._trace_row(self.step_n), fading=self._draws("step").get("fading"))
+            self._env.step_trace(self._action_dev(a), self._trace_row(self.step_n), fading=self._draws("step").get("fading"))
         r_dissect, reward, done, _ = self._finish_step()
         return np.array(self.state), reward, done, [r_dissect, self.step_n]
 
@@ -197,7 +214,7 @@ class MobiEnvironment:
         import torch
 
         a = self._action(action)
-        at = torch.tensor([a], dtype=torch.int64, device=self._env.device)
+        at = self._action_dev(a)
         if self.mobility_model == "read_trace":
             self._env.step_trace(at, self._trace_row(self.step_n), fading=self._draws("step").get("fading"))  # :202-203
         else:
