@@ -128,7 +128,7 @@ def test_relu6_bwd_and_value_head_kernels():
 
 def _rows_grad_case(torch, A, idx, H, S, two):
     M, K = idx.shape
-    g = torch.randn(M, (2 if two else 1) * H, device="cuda")
+    g = torch.randn(M, (2 if two else 1) * H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(M + H))
     dw0 = torch.full((S, H), 9.0, device="cuda")
     dw1 = torch.full((S, H), 9.0, device="cuda") if two else None
     ws = A.rows_grad_workspace(M, K, g.shape[1], S, "cuda")
