@@ -400,7 +400,12 @@ class A2CRunner:
 
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return self.flat.n_real, 1.0
-        dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM)
+        if self.flat.g.is_cuda and dist.get_backend() == "gloo":      # rehearsal on a one-GPU box (several ranks share the
+            host = self.flat.g.cpu()                                  # card, RCCL refuses that): reduce through the host
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.g.copy_(host)
+        else:
+            dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM)
         return self.flat.n_real, 1.0 / dist.get_world_size()
 
     def _ensure_update_buffers(self, M, K):
