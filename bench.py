@@ -11,9 +11,11 @@ N>1: the same workload per rank (weak scaling); env instances are independent, s
 env bench -- only the barrier / max-reduce of the timing.  `python bench.py --gpus N` WITHOUT a launcher starts its own N
 ranks (one process per GPU, spawned before anything touches the GPU) and fails loudly if fewer than N joined.
 
---launch  how the K step() launches reach the GPU (the kernel is the same single-step kernel for graph / eager):
-            graph  (default) hipGraph replay of chunks of <= 100 captured uavenv_step launches: one kernel per step, no per-step
-                   host cost.  From Python a launch costs ~8 us of host time (tools/host_floor.py), as much as the 4096-env kernel.
+--launch  how the K step() launches reach the GPU (the kernel is the same single-step kernel for seq / graph / eager):
+            seq    (default) uavenv_step_seq: one kernel per step, the launches of <= 100 steps issued by ONE C call.  From Python
+                   a launch costs ~8 us of host time (tools/host_floor.py), as much as the 4096-env kernel; from C ~2 us.
+            graph  hipGraph replay of chunks of <= 100 captured uavenv_step launches (same steady state; a replay costs 10-20 us
+                   of host latency before the first kernel, which a 20-step run feels)
             eager  one ctypes call per step (round 1's bench)
             many   uavenv_step_many: <= 100 steps per launch, state carried in registers (open-loop callers only)
 --mode a2c  BASELINE configs[2] (N=1) / configs[3] (N=8): 8192 envs per GPU, MLP actor-critic, 50-step rollouts, one update per
@@ -206,7 +208,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
     ap.add_argument("--mode", choices=("env", "a2c"), default="env")
-    ap.add_argument("--launch", choices=("graph", "eager", "many"), default="graph")
+    ap.add_argument("--launch", choices=("seq", "graph", "eager", "many"), default="seq")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-a2c", action="store_true", help="env mode: skip the appended A2C / gradient all-reduce measurement")
     ap.add_argument("--no-alt", action="store_true", help="env mode: skip the secondary eager / step_many measurements")
@@ -309,6 +311,8 @@ class EnvRun:
             self.cursor += n
             if self.launch == "graph":
                 self.graphs[n].replay()
+            elif self.launch == "seq":
+                env.step_seq(self.tape[:n])
             elif self.launch == "many":
                 env.step_many(self.tape[:n], out=self.many_out[n], refresh_out=False)
             else:
@@ -487,7 +491,7 @@ def main(argv=None):
             a2c = {"error": "%s: %s" % (type(ex).__name__, ex)}
     alt = {}
     if not args.no_alt and world == 1:                 # secondary: the other launch forms on the same box, same K / W
-        for other in ("eager", "many", "graph"):
+        for other in ("eager", "many", "graph", "seq"):
             if other != args.launch:
                 el, gm = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
                 alt[other] = {"value": E * K / el, "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
@@ -528,7 +532,8 @@ def main(argv=None):
             "dtype": "f64", "data": "synthetic", "launch": args.launch, "prewarm_steps_on_scratch_env": PREWARM_STEPS,
             "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=100, HIP step(), compact outputs, "
                                    "on-device Philox, %s" % (E, n_bs, n_ue, ",".join(str(g) for g in groups),
-                                                             {"graph": "one kernel per step, hipGraph replay of <=100-step chunks",
+                                                             {"seq": "one kernel per step, launches issued by one C call (uavenv_step_seq) per <=100 steps",
+                                                              "graph": "one kernel per step, hipGraph replay of <=100-step chunks",
                                                               "eager": "one kernel launch per step from Python",
                                                               "many": "uavenv_step_many, <=100 steps per launch"}[args.launch]),
                        "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": GRID, "parallelism": "env-shard x%d" % world},

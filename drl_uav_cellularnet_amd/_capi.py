@@ -51,7 +51,7 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_trace",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10")
 
@@ -91,6 +91,7 @@ def load():
     lib.uavenv_reset_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step_seq.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_obs_dense.argtypes = [_P, _P, _P]
     lib.uavenv_obs_dense_update.argtypes = [_P, _P, _P]

@@ -238,6 +238,19 @@ class BatchedMobiEnv:
         g._uavenv_keep = (a, self)                       # the graph holds raw pointers into both
         return g
 
+    def step_seq(self, actions):
+        """len(actions) step() launches issued by ONE C call (uavenv_step_seq): one kernel per step like step(), without the
+        per-step Python -> ctypes round trip.  ``actions`` int64 [T, N] on this device; ``self.out`` holds the last step's
+        results afterwards, as after T step() calls."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()
+                and a.dim() == 2 and a.shape[1] == self.n_envs):
+            raise ValueError("actions must be a contiguous int64 [T, n_envs] tensor on the env's device")
+        _capi.check(self._lib.uavenv_step_seq(self._h, a.data_ptr(), int(a.shape[0]), self._out_ref, self._stream()))
+        o = self.out
+        return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
+                                                             "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
+
     def step_many(self, actions, out=None, refresh_out=True):
         """T consecutive step() calls in ONE launch (uavenv_step_many) for actions that do not depend on the observations in
         between: ``actions`` int64 [T, N] on this device.  Returns a dict of [T, ...] tensors (block t = what step t returned;

@@ -447,6 +447,19 @@ extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_s
     return UAVENV_OK;
 }
 
+extern "C" int uavenv_step_seq(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream) {
+    if (!h || !actions_dev || n_steps < 0) return fail(UAVENV_E_INVALID, "step_seq: null handle / actions or negative n_steps");
+    DeviceGuard guard(h->device);
+    KParams p = h->kp;
+    fill_call(p, nullptr, out);
+    p.n_ticks = 1;
+    for (int t = 0; t < n_steps; ++t) {          // n_steps ordinary single-step launches, one host call: ~2 us each instead of the
+        p.actions = (const long long *)actions_dev + (long long)t * h->N;   // ~8 us a Python -> ctypes -> launch round trip costs
+        if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
+    }
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
                                  const UavEnvInject *inj, const UavEnvOut *out, void *stream) {
     if (!h || !actions_dev || !ue_xy_in_dev) return fail(UAVENV_E_INVALID, "step_trace: null handle, actions or trace");

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 3   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many */
+#define UAVENV_ABI_VERSION 3   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -132,6 +132,11 @@ int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj
  * keep stepping with done = 1.  n_ue <= 64: walker / group / UAV state stays in registers across the steps (no per-step launch,
  * state load or state store); n_ue > 64: n_steps single-step launches on `stream`. */
 int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream);
+/* The same n_steps steps as n_steps ordinary launches of the single-step kernel issued by ONE host call: step t reads row t of
+ * actions_dev [n_steps, N]; `out` is the single-step output set, overwritten by every step (it holds the last step's results
+ * afterwards), exactly as n_steps calls of uavenv_step would leave it.  For callers that pay a high price per host call
+ * (Python: ~8 us per ctypes round trip, as much as a 4096-env kernel) but want one kernel per step. */
+int uavenv_step_seq(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream);
 /* MobiEnvironment.step_test in read_trace mode (mobile_env.py:196-233): UE cells come from ue_xy_in_dev [N,U,2]. */
 int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const int16_t *ue_xy_in_dev,
                       const UavEnvInject *inj, const UavEnvOut *out, void *stream);

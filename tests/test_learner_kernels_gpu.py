@@ -143,7 +143,10 @@ def _rows_grad_case(torch, A, idx, H, S, two):
     g64 = g[:, :H].double()
     for r in torch.unique(idx[idx >= 0])[:5].tolist():
         cnt = (idx == r).sum(dim=1).double()
-        torch.testing.assert_close(dw0[r].double(), (cnt.unsqueeze(1) * g64).sum(dim=0), rtol=1e-4, atol=1e-4)
+        want = (cnt.unsqueeze(1) * g64).sum(dim=0)
+        # float32 accumulation of up to 120 000 terms: the error bound grows with the number of terms, not with the result
+        tol64 = 2e-6 * float(cnt.sum()) ** 0.5 * float(g64.abs().max()) + 1e-5
+        torch.testing.assert_close(dw0[r].double(), want, rtol=1e-4, atol=tol64)
     again = torch.empty_like(dw0)
     A.rows_grad(idx, g, H, S, again, torch.empty_like(dw0) if two else None, ws)
     assert torch.equal(again, dw0)

@@ -115,6 +115,20 @@ def test_step_many_skips_null_outputs_and_rejects_bad_arguments():
         env.step_many(act, out={"reward": rew})
 
 
+def test_step_seq_is_bit_identical_to_single_steps():
+    torch = _torch()
+    for n, n_bs, n_ue in ((4096, 4, 20), (5, 16, 200)):
+        env = _env(n, n_bs, n_ue)
+        ref = env.clone()
+        tape = _actions(torch, env, 9, 31)
+        env.step_seq(tape)
+        for t in range(9):
+            ref.step(tape[t])
+        for k, v in ref.out.items():
+            assert torch.equal(env.out[k], v), k
+        assert np.array_equal(env.get_state(), ref.get_state())
+
+
 def test_graph_replay_of_steps_is_bit_identical_to_eager():
     torch = _torch()
     env = _env(4096, 4, 20)
