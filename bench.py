@@ -64,19 +64,19 @@ def transcendental_evals_per_env_step(U, B):
 STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true, false>"   # rocprofv3 name (template part) of the single-step kernel of this workload
 
 
-def committed_counters(envs):
-    """Per-launch PMC figures of the step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
+def committed_counters(envs, kernel):
+    """Per-launch PMC figures of a step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
     cannot run the profiler on itself, so these are constants of the profiled build, labelled as such in the line.  None when
-    that file describes another kernel / batch size."""
+    that file does not describe this kernel / batch size."""
     path = os.path.join(ROOT, "profiles", "traffic_current.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return None
-    if t.get("kernel") != STEP_KERNEL or t.get("envs") != envs or t.get("n_ue") != N_UE or t.get("n_bs") != N_BS:
+    if t.get("envs") != envs or t.get("n_ue") != N_UE or t.get("n_bs") != N_BS:
         return None
-    return t
+    return t.get("kernels", {}).get(kernel)
 
 
 def cpu_baseline(target_seconds=12.0):
@@ -519,29 +519,32 @@ def main(argv=None):
         per_step_s = gpu_ms * 1e-3 / K   # average per-step device time (HIP events on the launch stream around the timed region)
         b_step = algorithmic_bytes_per_env_step(n_ue, n_bs, len(groups))
         achieved = b_step * E / per_step_s / 1e9
-        cnt = committed_counters(E) if (baseline_shape and args.launch != "many") else None
+        many = args.launch == "many"
+        kernel = STEP_KERNEL.replace("false>", "true>") if many else STEP_KERNEL
+        spl = min(CHUNK, K) if many else 1                      # steps one launch of the dominant kernel processes
+        cnt = committed_counters(E, kernel) if baseline_shape else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None, "traffic_source": None,
-                "kernel": (STEP_KERNEL if args.launch != "many" else STEP_KERNEL.replace("false>", "true>")) if baseline_shape
-                else "env kernel of this shape (secondary measurement)",
-                "algorithmic_bytes_per_launch": b_step * E * (1 if args.launch != "many" else min(CHUNK, K)),
-                "avg_launch_us": per_step_s * 1e6 * (1 if args.launch != "many" else min(CHUNK, K)),
+                "kernel": kernel if baseline_shape else "env kernel of this shape (secondary measurement)",
+                "steps_per_launch": spl,
+                "algorithmic_bytes_per_launch": b_step * E * spl,
+                "avg_launch_us": per_step_s * 1e6 * spl,
                 "avg_step_us": per_step_s * 1e6,
                 "transcendental_evals_per_step": transcendental_evals_per_env_step(n_ue, n_bs) * E,
                 "transcendental_evals_per_s": transcendental_evals_per_env_step(n_ue, n_bs) * E / per_step_s}
         if cnt is not None:
             # FETCH_SIZE on gfx950 counts 64 B per 128-B request for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM):
-            # every state load of this kernel is such a dwordx4 record load, hence the x2; WRITE_SIZE is exact.
-            fetch = 2 * int(cnt["fetch_size_bytes_raw"])
-            roof["traffic"] = fetch + int(cnt["write_size_bytes_raw"])
-            roof["traffic_over_algorithmic"] = roof["traffic"] / float(b_step * E)
+            # every state load of these kernels is such a dwordx4 record load, hence the x2; WRITE_SIZE is exact.  The committed
+            # figures are per launch of cnt["steps_per_launch"] steps; scaled to this run's steps per launch.
+            scale = spl / float(cnt["steps_per_launch"])
+            roof["traffic"] = int((2 * int(cnt["fetch_size_bytes_raw"]) + int(cnt["write_size_bytes_raw"])) * scale)
+            roof["traffic_over_algorithmic"] = roof["traffic"] / float(b_step * E * spl)
             roof["traffic_source"] = ("profiles/traffic_current.json: committed rocprofv3 PMC passes of this kernel (FETCH_SIZE x2 "
                                       "gfx950 correction + WRITE_SIZE), NOT measured by this run")
-            if cnt.get("valu_insts_per_wave") and cnt.get("waves_per_launch"):
-                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-                roof["valu_issue_frac"] = (cnt["valu_insts_per_wave"] * cnt["waves_per_launch"]) / (n_simd * SIMD_ISSUE_HZ * per_step_s)
-                roof["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed profile) / (%d SIMDs x 0.6 G wave-instr/s) / measured "
-                                           "step time: the roof that actually bounds this float64-ALU kernel" % n_simd)
+            n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            roof["valu_issue_frac"] = (cnt["valu_insts_per_launch"] * scale) / (n_simd * SIMD_ISSUE_HZ * per_step_s * spl)
+            roof["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed profile) / (%d SIMDs x 0.6 G wave-instr/s) / measured "
+                                       "launch time: the roof that actually bounds this float64-ALU kernel" % n_simd)
         line = {
             "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
             "unit": "env-steps/s", "n_gpus": n_ranks, "steps": K, "warmup": W,
@@ -552,7 +555,7 @@ def main(argv=None):
                                                              {"seq": "one kernel per step, launches issued by one C call (uavenv_step_seq) per <=100 steps",
                                                               "graph": "one kernel per step, hipGraph replay of <=100-step chunks",
                                                               "eager": "one kernel launch per step from Python",
-                                                              "many": "uavenv_step_many, <=100 steps per launch"}[args.launch]),
+                                                              "many": "uavenv_step_many: <=100 consecutive steps per launch, state carried in registers between them, all nine outputs of every step written"}[args.launch]),
                        "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": GRID, "parallelism": "env-shard x%d" % world},
             "roofline": roof,
         }
