@@ -53,7 +53,7 @@ class UavEnvStateLayout(C.Structure):
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
            "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area",
-           "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10")
+           "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
 
 _lib = None
 
@@ -101,6 +101,7 @@ def load():
     lib.uavenv_set_state.argtypes = [_P, _P, C.c_int, _P]
     lib.uavenv_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.uavenv_philox4x32_10.restype = None
+    lib.uavenv_lean_math_eval.argtypes = [C.c_int, _P, _P, _P, _P, C.c_int64, _P]
     if lib.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError("libuavenv.so ABI version mismatch")
     _lib = lib

@@ -543,6 +543,37 @@ extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float
     return UAVENV_OK;
 }
 
+// The device code paths of csrc/lean_math.h, callable on arrays: lets tests measure the accuracy of what the kernels execute
+// (v_rcp_f64 / v_rsq_f64 seeds, contracted FMAs), not only of the host stand-ins.
+__global__ __launch_bounds__(256) void lean_math_kernel(int op, const double *a, const double *b, double *o0, double *o1, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LeanCoef C = lm_make_coef<false>();
+    const double x = a[i];
+    double r0 = 0.0, r1 = 0.0;
+    switch (op) {
+        case 0: r0 = lm_div(x, b[i]); break;
+        case 1: r0 = lm_rsqrt(x); break;
+        case 2: r0 = lm_logc(x, C); break;
+        case 3: r0 = lm_exp2(x, C); break;
+        case 4: lm_sincospi(x, C, &r0, &r1); break;
+        default: break;
+    }
+    o0[i] = r0;
+    if (o1 != nullptr) o1[i] = r1;
+}
+
+extern "C" int uavenv_lean_math_eval(int op, const double *a_dev, const double *b_dev, double *out0_dev, double *out1_dev, int64_t n,
+                                     void *stream) {
+    if (op < 0 || op > 4 || n < 0 || (n > 0 && (!a_dev || !out0_dev)) || (op == 0 && n > 0 && !b_dev) || (op == 4 && n > 0 && !out1_dev))
+        return fail(UAVENV_E_INVALID, "lean_math_eval: bad op / null buffer");
+    if (n == 0) return UAVENV_OK;
+    hipLaunchKernelGGL(lean_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a_dev, b_dev, out0_dev,
+                       out1_dev, (long long)n);
+    HIP_TRY(hipGetLastError());
+    return UAVENV_OK;
+}
+
 #ifdef UAVENV_STAMPS
 // Diagnostic builds only (not in include/uavenv.h): where the kernels drop their s_memtime stamps.
 extern "C" int uavenv_debug_set_stamp_buffer(uavenv_t *h, void *dev_ptr) {

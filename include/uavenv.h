@@ -164,6 +164,11 @@ int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout);
 int uavenv_get_state(uavenv_t *h, void *dst, int dst_is_device, void *stream);
 int uavenv_set_state(uavenv_t *h, const void *src, int src_is_device, void *stream);
 
+/* The float64 primitives the kernels compute with (csrc/lean_math.h), evaluated ON THE DEVICE over arrays of n doubles on the current
+ * device: op 0 a/b (lm_div: b positive normal), 1 1/sqrt(a), 2 ln(a), 3 2^a, 4 sin(pi a) -> out0, cos(pi a) -> out1.  Test hook:
+ * tests/test_lean_math_gpu.py measures their error against long double. */
+int uavenv_lean_math_eval(int op, const double *a_dev, const double *b_dev, double *out0_dev, double *out1_dev, int64_t n, void *stream);
+
 /* Philox4x32-10 of one counter/key on the HOST (known-answer tests of the generator the kernels use). */
 void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
