@@ -419,7 +419,7 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
             "allreduce_ms_per_update": st.get("allreduce_ms"), "grad_allreduce_bytes": grad_allreduce_bytes(runner.net),
             "allreduce": ("RCCL (nccl backend), one flat bucket per update" if (world > 1 and args.backend == "nccl")
                           else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
-            "collect_launch": getattr(runner, "collect_launch", "eager"),
+            "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
             "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
             "config": "8192 envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, 50-step rollouts, 1 update per rollout"}
 

@@ -202,6 +202,40 @@ def sample_actions(prob, generator=None, uniforms=None):
     return torch.searchsorted(cdf, u, right=True).squeeze(1).clamp_(max=prob.shape[1] - 1)
 
 
+_TUNABLE_DONE = False
+
+
+def enable_gemm_tuning(max_ms=400):
+    """Let PyTorch's TunableOp pick the fastest rocBLAS / hipBLASLt solution per GEMM shape.  The defaults run the learner's
+    K = 200 shapes and its 409 600-deep weight-gradient reductions at 34-73 TFLOP/s; the tuned picks reach 45-108
+    (profiles/r02f_gemm_tunableop.txt: the update's seven large GEMMs 7.3 -> 5.2 ms).  Picks for the BASELINE config 3 shapes ship
+    in data/tunableop_gfx950.csv (valid for this image's ROCm / hipBLASLt build: TunableOp checks the versions recorded in the file
+    and ignores it otherwise); any other shape is tuned at first use for at most ``max_ms``, outside graph capture (the rollout graph
+    is captured after an eager warm-up pass).  Once per process; a no-op without a GPU or without torch.cuda.tunable."""
+    global _TUNABLE_DONE
+    if _TUNABLE_DONE or not torch.cuda.is_available():
+        return _TUNABLE_DONE
+    try:
+        import os
+        import shutil
+        import tempfile
+
+        import torch.cuda.tunable as tun
+
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tunableop_gfx950.csv")
+        dst = os.path.join(tempfile.mkdtemp(prefix="uavagent_tunable_"), "tunableop_results.csv")   # TunableOp rewrites its file at exit
+        if os.path.isfile(src):
+            shutil.copyfile(src, dst)
+        tun.set_filename(dst)
+        tun.set_max_tuning_duration(int(max_ms))
+        tun.enable(True)
+        tun.tuning_enable(True)
+        _TUNABLE_DONE = True
+    except Exception:                                        # an optional speed-up: never a reason to fail
+        _TUNABLE_DONE = False
+    return _TUNABLE_DONE
+
+
 PARAM_ORDER = ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3", "c_w1", "c_b1", "c_w2", "c_b2", "c_w3", "c_b3")
 N_ACTOR_PARAMS = 6
 
@@ -249,9 +283,10 @@ class A2CRunner:
     around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=True):
         self.env = env
         self.dev = env.device
+        self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
         self.G, self.B = env.grid_n, env.nBS
         self.net = (net if net is not None else ACNet(env.observation_space_dim, env.action_space_dim, seed=seed)).to(self.dev)
         self.flat = FlatParams(self.net)

@@ -38,7 +38,18 @@ def main():
         ("dW   [200,M]x[M,625]", lambda: torch.mm(x.t(), d, out=g_w3), 2 * M * H * NA),
         ("dW   [200,M]x[M,200]", lambda: torch.mm(x.t(), x, out=g_w2), 2 * M * H * H),
     ]
-    for lib in ("default", "hipblaslt"):
+    for lib in ("default", "hipblaslt", "tunableop"):
+        if lib == "tunableop":
+            try:
+                import torch.cuda.tunable as tun
+
+                tun.enable(True)
+                tun.tuning_enable(True)
+                tun.set_max_tuning_duration(2000)
+                tun.set_filename("/tmp/tunableop_results.csv")
+            except Exception as ex:
+                print("tunableop not available:", ex)
+                break
         if lib == "hipblaslt":
             try:
                 torch.backends.cuda.preferred_blas_library("hipblaslt")
