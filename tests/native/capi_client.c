@@ -1,5 +1,5 @@
 /* A plain C client of include/uavenv.h (TEST INFRASTRUCTURE): no Python, no torch -- hipMalloc'd buffers, the null stream.
- * Build (tests/test_capi_c_client_gpu.py does it):  hipcc -x c tests/native/capi_client.c -Iinclude -L<lib dir> -luavenv
+ * Build (tests/test_capi_c_client_gpu.py does it):  gcc -D__HIP_PLATFORM_AMD__ capi_client.c -I$ROCM/include -Iinclude -L<lib dir> -luavenv -L$ROCM/lib -lamdhip64
  * Prints one line per step: step_n of env 0, sum of rewards, sum of serving indices, first UE cell -- the Python test compares
  * them with BatchedMobiEnv on the same seed.  Mirrors what a maintainer's binding does: default_config -> create -> init ->
  * warmup(200) -> reset -> step* -> step_many -> destroy. */

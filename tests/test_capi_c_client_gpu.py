@@ -20,8 +20,11 @@ def test_c_client_matches_the_python_binding(tmp_path):
 
     lib_dir = os.path.dirname(build.build())
     exe = os.path.join(tmp_path, "capi_client")
-    subprocess.check_call([build.hipcc_path(), "-x", "c", os.path.join(ROOT, "tests", "native", "capi_client.c"), "-I",
-                           os.path.join(ROOT, "include"), "-L", lib_dir, "-luavenv", "-Wl,-rpath," + lib_dir, "-o", exe])
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(build.hipcc_path())))          # .../rocm/bin/hipcc -> .../rocm
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "native", "capi_client.c"),
+                           "-I", os.path.join(rocm, "include"), "-I", os.path.join(ROOT, "include"), "-L", lib_dir, "-luavenv",
+                           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe])
     N, T = 300, 5
     lines = subprocess.check_output([exe, str(N)], text=True, timeout=300).splitlines()
     assert lines[-1].startswith("error step: null handle or actions")
