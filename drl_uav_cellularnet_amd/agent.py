@@ -379,9 +379,16 @@ class A2CRunner:
         until the next collect()."""
         env, T = self.env, self.T
         self.u_buf.copy_(torch.rand(self.u_buf.shape, device=self.dev, dtype=torch.float32, generator=self.gen))
-        if self.collect_launch == "graph" and self.dev.type == "cuda":
-            if self._graph is None:
+        if self.collect_launch == "graph" and self.dev.type == "cuda" and self._graph is None:
+            try:
                 self._capture()
+            except Exception as ex:      # a failed capture executes nothing (the warm-up pass has been rolled back): run eagerly
+                import warnings
+
+                warnings.warn("A2CRunner: hipGraph capture of the rollout failed (%s: %s); collecting eagerly" % (type(ex).__name__, ex))
+                self.collect_launch = "eager"
+                self._graph = None
+        if self.collect_launch == "graph" and self._graph is not None:
             self._graph.replay()
         else:
             self._rollout_steps()
@@ -416,8 +423,10 @@ class A2CRunner:
         for k, v in keep.items():
             env.out[k].copy_(v)
         self.idx_buf[self.T].copy_(keep_idx)
+        # capture_error_mode="thread_local": with torch.distributed initialised, RCCL's watchdog thread polls events while this
+        # thread captures; in the default "global" mode that invalidates the capture.
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._rollout_steps()
         self._graph = g
 

@@ -231,7 +231,7 @@ class BatchedMobiEnv:
                 and a.dim() == 2 and a.shape[1] == self.n_envs):
             raise ValueError("actions must be a contiguous int64 [T, n_envs] tensor on the env's device")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (other threads, e.g. RCCL's watchdog, may poll events meanwhile)
             stream = self._stream()                      # the capturing stream
             for t in range(int(a.shape[0])):
                 _capi.check(self._lib.uavenv_step(self._h, a[t].data_ptr(), None, self._out_ref, stream))
