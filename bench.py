@@ -421,7 +421,8 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
                           else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
             "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
             "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
-            "config": "8192 envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, 50-step rollouts, 1 update per rollout"}
+            "config": "%d envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, %d-step rollouts, 1 update per rollout"
+                      % (envs, rollout_len)}
 
 
 def main(argv=None):
