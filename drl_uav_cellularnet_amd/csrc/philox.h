@@ -14,7 +14,7 @@
 namespace uavk {
 
 enum DrawSite : uint32_t {  // Philox counter word 3
-    DOM_FADING = 1, DOM_HEADING_RETIRED = 2 /* headings now come from the spare words of DOM_FADING calls */, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
+    DOM_FADING = 1, DOM_HEADING = 2 /* quad mode (B > 8) only; otherwise headings come from the spare words of DOM_FADING calls */, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
     DOM_INIT_UE_A = 5, DOM_INIT_UE_B = 6, DOM_INIT_G_A = 7, DOM_INIT_G_B = 8, DOM_INIT_G_C = 9, DOM_AREA = 10
 };
 

@@ -240,6 +240,11 @@ __device__ __forceinline__ void philox_u2(const KParams &p, uint32_t env, uint32
 //   heading uniform drawn this tick = u53(q_0.w, q_1.w)  (HB >= 2)   or   q_0.w * 2^-32  (HB == 1)
 // Two Philox calls per UE and tick instead of three: the quarter-rate 32x32->64 multiplies of Philox were ~17 % of
 // the step kernel's issue cycles.
+// QUAD mode, B > 8 (the 16 / 32-UAV shapes are VALU-issue bound and Philox was 19 % of it): one call serves FOUR UAVs,
+//   call c of walker u:  q_c = Philox(ctr = (env, tick, u*QB + c, DOM_FADING)),  QB = ceil(B/4)
+//   UAVs 4c, 4c+1: radius uniform q_c.x * 2^-32, angle fraction q_c.y * 2^-32;   UAVs 4c+2, 4c+3: q_c.z and q_c.w
+//   heading uniform = u53(h.x, h.y),  h = Philox(ctr = (env, tick, u, DOM_HEADING)).
+__host__ __device__ constexpr bool quad_draws(int B) { return B > 8; }
 __device__ __forceinline__ U4 philox_raw(const KParams &p, uint32_t env, uint32_t tick, uint32_t idx, uint32_t dom) {
     return philox4x32_10(p.env_id_base + env, tick, idx, dom, p.key0, p.key1);
 }
@@ -417,6 +422,8 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
                                          const U4 &q0, const U4 &q1, double pg[BT]) {
     // PRE: q0 / q1 are this walker's calls 0 and 1, already made for the heading of the same tick.
     const int B = uav_count<BT, FAST>(p.B);
+    U4 qq = {0u, 0u, 0u, 0u};   // quad mode: the current four-UAV call
+    (void)qq;
 #pragma unroll
     for (int b2 = 0; b2 < BT; b2 += 2) {
         double f0 = 0.0, f1 = 0.0;
@@ -426,6 +433,18 @@ __device__ __forceinline__ void rx_power(const KParams &p, const HotConst &H, co
                     f0 = p.inj_fading[iu * B + b2];
                     if (b2 + 1 < B) f1 = p.inj_fading[iu * B + b2 + 1];
                 }
+            } else if (quad_draws(B)) {
+                // quad mode (B > 8; a compile-time fact in the FAST variants, where B == BT): one Philox call per four UAVs,
+                // 32-bit radius uniform and angle fraction per pair
+                if ((b2 & 3) == 0) qq = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 3) >> 2) + (b2 >> 2)), DOM_FADING);
+                const uint32_t wr = (b2 & 3) == 0 ? qq.x : qq.z, wa = (b2 & 3) == 0 ? qq.y : qq.w;
+                const double u0 = (double)wr * (1.0 / 4294967296.0);
+                const double t = -2.0 * lm_logc(1.0 - u0, C);      // 1-u0 in [2^-32, 1]
+                const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;
+                double sa, ca;
+                lm_sincospi((double)wa * (1.0 / 2147483648.0), C, &sa, &ca);
+                f0 = H.sh_mean + H.sh_sd * (r * ca);
+                f1 = H.sh_mean + H.sh_sd * (r * sa);
             } else {
                 const U4 q = (PRE && b2 == 0) ? q0 : ((PRE && b2 == 2) ? q1 :
                              philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * ((B + 1) >> 1) + (b2 >> 1)), DOM_FADING));
@@ -807,10 +826,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             }
             if (UAV_INJ(p.inj_theta)) hu = hu_inj;                                       // new heading (:508)
             else {
-                const int HB = (B + 1) >> 1;
-                q0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
-                q1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : q0;
-                hu = heading_from(q0, q1, HB);
+                if (quad_draws(B)) {                                    // B > 8: the heading has its own call (B is the run-time
+                                                                        // count in the checked variants: the warm-up kernel has BT = 4)
+                    const U4 hq = philox_raw(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING);
+                    hu = u53(hq.x, hq.y);
+                } else {
+                    const int HB = (B + 1) >> 1;
+                    q0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
+                    q1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : q0;
+                    hu = heading_from(q0, q1, HB);
+                }
             }
             if (gown) group_finish<FAST>(p, C, e, ul, tick, touched, MAXC, ogfl, ogv, ogc, ogs);   // :493-521
             if (aggregating) { agg -= 1; if (agg == 0) deagg = p.deagg_len; }            // :472-473
@@ -930,6 +955,16 @@ __device__ __forceinline__ void fading_pair(const HotConst &H, const LeanCoef &C
     f0 = H.sh_mean + H.sh_sd * (r * ca);
     f1 = H.sh_mean + H.sh_sd * (r * sa);
 }
+// Quad mode: the same Box-Muller pair from two 32-bit words (radius uniform, angle fraction).
+__device__ __forceinline__ void fading_pair32(const HotConst &H, const LeanCoef &C, uint32_t wr, uint32_t wa, double &f0, double &f1) {
+    const double u0 = (double)wr * (1.0 / 4294967296.0);
+    const double t = -2.0 * lm_logc(1.0 - u0, C);        // 1 - u0 in [2^-32, 1]
+    const double r = (t > 0.0) ? t * lm_rsqrt(t) : 0.0;
+    double sa, ca;
+    lm_sincospi((double)wa * (1.0 / 2147483648.0), C, &sa, &ca);
+    f0 = H.sh_mean + H.sh_sd * (r * ca);
+    f1 = H.sh_mean + H.sh_sd * (r * sa);
+}
 // Received power of one UAV at one walker: the arithmetic of rx_power()'s inner block (channel.py:220-257).
 template <bool PLC>
 __device__ __forceinline__ double rx_gain(const HotConst &H, const LeanCoef &C, int ix, int iy, int bx, int by, double f) {
@@ -990,6 +1025,8 @@ void env_kernel_multipass(const KParams p) {
 
     const int U = p.U, B = uav_count<BT, FAST>(p.B), Gr = p.Gr;
     const int HB = (B + 1) >> 1;
+    const bool quad = quad_draws(B);                   // B > 8: four UAVs per Philox call, heading from its own call
+    const int QB = (B + 3) >> 2;
     const double MAXC = H.maxc;
     const int n_full = U >> 6, R = U & 63;
     const int n_pass = n_full + (R ? 1 : 0);
@@ -1080,7 +1117,10 @@ void env_kernel_multipass(const KParams p) {
                     }
                 }
                 if (UAV_INJ(p.inj_theta)) { if (act) hu = p.inj_theta[iu]; }
-                else {
+                else if (quad) {
+                    const U4 hq = philox_raw(p, (uint32_t)e, tick, (uint32_t)u, DOM_HEADING);
+                    hu = u53(hq.x, hq.y);
+                } else {
                     h0 = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB), DOM_FADING);
                     h1 = (HB >= 2) ? philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + 1), DOM_FADING) : h0;
                     hu = heading_from(h0, h1, HB);
@@ -1105,12 +1145,16 @@ void env_kernel_multipass(const KParams p) {
                 // so nothing is ever subtracted), and for the serving UAV its power and the sum of the others in index order.
                 double bp = 0.0, others_b = 0.0, ps = 0.0, others_s = 0.0;
                 best = 0;
+                U4 qq = {0u, 0u, 0u, 0u};                                       // quad mode: the current four-UAV call
 #pragma unroll 1
                 for (int k = 0; k < HB; ++k) {
                     const int b0 = 2 * k, b1 = 2 * k + 1;
                     double f0 = 0.0, f1 = 0.0;
                     if (UAV_INJ(p.inj_fading)) {
                         if (act) { f0 = p.inj_fading[iu * B + b0]; if (b1 < B) f1 = p.inj_fading[iu * B + b1]; }
+                    } else if (quad) {
+                        if ((k & 1) == 0) qq = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * QB + (k >> 1)), DOM_FADING);   // (k is wave-uniform)
+                        fading_pair32(H, C, (k & 1) ? qq.z : qq.x, (k & 1) ? qq.w : qq.y, f0, f1);
                     } else {
                         U4 q = (k == 0) ? h0 : h1;                              // PRE: this walker's calls 0 / 1 exist already
                         if (!PRE || k >= 2) q = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + k), DOM_FADING);   // (k is wave-uniform)
@@ -1138,6 +1182,9 @@ void env_kernel_multipass(const KParams p) {
                 double f0 = 0.0, f1 = 0.0;
                 if (UAV_INJ(p.inj_fading)) {
                     if (act) { f0 = p.inj_fading[iu * B + b0]; if (b1 < B) f1 = p.inj_fading[iu * B + b1]; }
+                } else if (quad) {
+                    const U4 q = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * QB + (hb >> 1)), DOM_FADING);
+                    fading_pair32(H, C, (hb & 1) ? q.z : q.x, (hb & 1) ? q.w : q.y, f0, f1);
                 } else {
                     const U4 q = (PRE && hb == 0) ? h0 : ((PRE && hb == 1) ? h1 :
                                  philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + hb), DOM_FADING));

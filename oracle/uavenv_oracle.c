@@ -41,7 +41,7 @@ void uavo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 }
 
 enum { /* Philox counter word 3: draw site */
-    DOM_FADING = 1, DOM_HEADING_RETIRED = 2 /* headings now come from the spare words of DOM_FADING calls */, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
+    DOM_FADING = 1, DOM_HEADING = 2 /* quad mode (n_bs > 8) only; otherwise headings come from the spare words of DOM_FADING calls */, DOM_GROUP_A = 3, DOM_GROUP_B = 4,
     DOM_INIT_UE_A = 5, DOM_INIT_UE_B = 6, DOM_INIT_G_A = 7, DOM_INIT_G_B = 8, DOM_INIT_G_C = 9, DOM_AREA = 10
 };
 
@@ -64,16 +64,27 @@ static void philox_u2(const UavoState *st, int64_t e, uint32_t tick, uint32_t id
  *   q_p.x, q_p.y -> 53-bit uniform of the Box-Muller radius;  q_p.z * 2^-32 -> angle fraction;  q_p.w -> spare
  *   heading uniform drawn this tick = u53(q_0.w, q_1.w)   (HB >= 2)   or   q_0.w * 2^-32   (HB == 1)
  * Two Philox calls per UE and tick instead of three (a separate heading call): the 32x32->64 multiplies of Philox
- * are quarter-rate on CDNA4 and were ~17 % of the step kernel's issue cycles. */
+ * are quarter-rate on CDNA4 and were ~17 % of the step kernel's issue cycles.
+ * QUAD mode, n_bs > 8 (round 2; the 16-UAV shapes are bound by VALU issue and Philox was 19 % of it): one call serves FOUR UAVs,
+ *   call c of walker u:  q_c = Philox(ctr = (env, tick, u*QB + c, DOM_FADING)),  QB = ceil(B/4)
+ *   UAVs 4c, 4c+1: radius uniform q_c.x * 2^-32, angle fraction q_c.y * 2^-32;   UAVs 4c+2, 4c+3: q_c.z and q_c.w
+ *   (32-bit radius uniforms: the normal's tail ends at sqrt(64 ln 2) = 6.66 sigma instead of 8.57)
+ *   heading uniform = u53(h.x, h.y),  h = Philox(ctr = (env, tick, u, DOM_HEADING)). */
 static void philox_raw(const UavoState *st, int64_t e, uint32_t tick, uint32_t idx, uint32_t dom, uint32_t o[4]) {
     uint32_t ctr[4] = {st->env_id_base + (uint32_t)e, tick, idx, dom};
     uint32_t key[2] = {(uint32_t)st->seed, (uint32_t)(st->seed >> 32)};
     uavo_philox4x32_10(ctr, key, o);
 }
 
+static int quad_mode(const UavoConfig *cfg) { return cfg->n_bs > 8; }
+
 static double heading_uniform(const UavoConfig *cfg, const UavoState *st, int64_t e, uint32_t tick, int u) {
     const int HB = (cfg->n_bs + 1) / 2;
     uint32_t o0[4], o1[4];
+    if (quad_mode(cfg)) {
+        philox_raw(st, e, tick, (uint32_t)u, DOM_HEADING, o0);
+        return u53(o0[0], o0[1]);
+    }
     philox_raw(st, e, tick, (uint32_t)(u * HB + 0), DOM_FADING, o0);
     if (HB >= 2) {
         philox_raw(st, e, tick, (uint32_t)(u * HB + 1), DOM_FADING, o1);
@@ -348,7 +359,24 @@ static void draw_fading(const UavoConfig *cfg, const UavoState *st, int64_t e, u
                         const UavoInject *inj, double *fading) {
     const int U = cfg->n_ue, B = cfg->n_bs, HB = (B + 1) / 2;
     if (inj && inj->fading) { memcpy(fading, inj->fading + e * U * B, sizeof(double) * U * B); return; }
-    /* np.random.normal(mean, sd) (channel.py:240) -> Box-Muller on Philox uniforms, two BSs per call */
+    /* np.random.normal(mean, sd) (channel.py:240) -> Box-Muller on Philox uniforms, two BSs per call (four in quad mode) */
+    if (quad_mode(cfg)) {
+        const int QB = (B + 3) / 4;
+        for (int u = 0; u < U; ++u)
+            for (int c = 0; c < QB; ++c) {
+                uint32_t o[4];
+                philox_raw(st, e, tick, (uint32_t)(u * QB + c), DOM_FADING, o);
+                for (int h = 0; h < 2; ++h) {
+                    const int b0 = 4 * c + 2 * h;
+                    if (b0 >= B) break;
+                    double r = sqrt(-2.0 * log(1.0 - (double)o[2 * h] * (1.0 / 4294967296.0)));
+                    double a = TWO_PI_NP * ((double)o[2 * h + 1] * (1.0 / 4294967296.0));
+                    fading[u * B + b0] = cfg->shadow_mean + cfg->shadow_sd * (r * cos(a));
+                    if (b0 + 1 < B) fading[u * B + b0 + 1] = cfg->shadow_mean + cfg->shadow_sd * (r * sin(a));
+                }
+            }
+        return;
+    }
     for (int u = 0; u < U; ++u)
         for (int p = 0; p < HB; ++p) {
             uint32_t o[4];
