@@ -472,7 +472,7 @@ def main(argv=None):
 
     if args.mode == "a2c":
         envs = args.envs or A2C_ENVS
-        rollouts = max(1, args.steps // A2C_ROLLOUT) if args.steps != 2000 else 6
+        rollouts = max(1, args.steps // A2C_ROLLOUT) if args.steps != 2000 else 6      # (2000 = the env bench's default: 6 rollouts)
         res = measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts)
         if rank == 0:
             line = {"metric": res["metric"], "value": res["value"], "unit": "env-steps/s", "n_gpus": n_ranks,
