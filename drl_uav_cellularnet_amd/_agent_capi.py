@@ -14,7 +14,7 @@ from . import build as _build
 EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_sum_f32", "uavagent_first_layer_f32",
            "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
-           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_rmsprop_tf1")
+           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1")
 ABI_VERSION = 2
 
 _lib = None
@@ -49,6 +49,7 @@ def load():
         "uavagent_relu6_bwd": [_P, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P],
         "uavagent_rowdot_f32": [_P, _P, _P, _I64, _I32, _P, _P],
         "uavagent_rows_grad_f32": [_P, _P, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, C.c_size_t, _P],
+        "uavagent_nstep_returns_f32": [_P, _P, _I64, _I32, _F, _P, _P],
         "uavagent_rmsprop_tf1": [_P, _P, _P, _I64, _F, _F, _F, _F, _P],
     }
     for name, args in sig.items():
@@ -204,6 +205,19 @@ def rows_grad(idx, g, h, n_rows, dw0, dw1, ws):
         rc = load().uavagent_rows_grad_f32(_ptr(idx), _ptr(g), M, K, int(h), n_tables, int(n_rows), _ptr(dw0), _ptr(dw1),
                                            C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream(g.device))
     _check(rc, "uavagent_rows_grad_f32")
+
+
+def nstep_returns(rewards, bootstrap, gamma, out=None):
+    """[T, N] value targets: out[t] = r[t] + gamma * out[t + 1], out[T] = bootstrap (agent.nstep_returns in one launch)."""
+    _f32c(rewards, "rewards")
+    _f32c(bootstrap, "bootstrap")
+    T, N = rewards.shape
+    if out is None:
+        out = torch.empty_like(rewards)
+    with torch.cuda.device(rewards.device):
+        rc = load().uavagent_nstep_returns_f32(_ptr(rewards), _ptr(bootstrap), N, T, float(gamma), _ptr(out), _stream(rewards.device))
+    _check(rc, "uavagent_nstep_returns_f32")
+    return out
 
 
 def rmsprop_tf1(w, ms, g, lr, decay=0.9, eps=1e-10, g_scale=1.0):

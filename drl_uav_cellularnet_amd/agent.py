@@ -465,7 +465,7 @@ class A2CRunner:
             fw = {"h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H), "logits": f(M, NA)}
         self._upd = {"M": M, "own": own, "h1a": fw["h1a"], "h1c": fw["h1c"], "h2a": fw["h2a"], "logits": fw["logits"],
                      "h2c": f(M, H), "dh": f(M, H),
-                     "gcat": f(M, 2 * H), "v": f(M), "dv": f(M), "loss": torch.zeros(3, dtype=torch.float64, device=dev),
+                     "gcat": f(M, 2 * H), "v": f(M), "dv": f(M), "target": f(M), "loss": torch.zeros(3, dtype=torch.float64, device=dev),
                      "ws_loss": A.loss_grad_workspace(NA, dev), "ws_relu": A.relu6_bwd_workspace(H, dev),
                      "ws_rows": A.rows_grad_workspace(M, K, 2 * H, self.net.n_state, dev)}
         return self._upd
@@ -480,9 +480,9 @@ class A2CRunner:
         net, fl = self.net, self.flat
         T, N, K = idx_buf.shape
         M, H = T * N, HIDDEN
-        target = nstep_returns(rew_buf, boot, self.gamma).reshape(M)
-        idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
         b = self._ensure_update_buffers(M, K)
+        target = A.nstep_returns(rew_buf.contiguous(), boot.contiguous(), self.gamma, out=b["target"].view(T, N)).reshape(M)
+        idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
         gv = fl.gv
         # forward: the actor's activations and both first layers were computed by the rollout itself, with these very weights
         reuse = b["own"] and self._fwd_valid and idx_buf.data_ptr() == self.idx_buf.data_ptr()

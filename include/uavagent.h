@@ -85,6 +85,11 @@ size_t uavagent_rows_grad_workspace_bytes(int64_t m_rows, int32_t k, int32_t n_c
 int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables,
                            int64_t n_rows, float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* n-step value targets of a rollout (a2c_single_thread.py:176-183): out[t, n] = r[t, n] + gamma * out[t+1, n], out[T, n] := bootstrap[n]
+ * (v(s_T), or 0 where the episode ended).  rewards / out f32 [n_steps, n_envs], bootstrap f32 [n_envs]. */
+int uavagent_nstep_returns_f32(const float *rewards, const float *bootstrap, int64_t n_envs, int32_t n_steps, float gamma, float *out,
+                               void *stream);
+
 /* tf.train.RMSPropOptimizer(lr, decay, momentum = 0, epsilon) as TF1 applies it (main.py:300-301), on flat buffers of n floats:
  *   gs = g * g_scale;  ms <- decay * ms + (1 - decay) * gs^2;  w <- w - lr * gs / sqrt(ms + epsilon). */
 int uavagent_rmsprop_tf1(float *w, float *ms, const float *g, int64_t n, float lr, float decay, float eps, float g_scale,

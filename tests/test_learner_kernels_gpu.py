@@ -197,6 +197,19 @@ def test_rmsprop_kernel_has_tf1_semantics():
     assert not torch.equal(w, w0)
 
 
+def test_nstep_returns_kernel():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+    from drl_uav_cellularnet_amd.agent import nstep_returns
+
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rew = torch.randn(50, 777, device="cuda", generator=g)
+    boot = torch.randn(777, device="cuda", generator=g)
+    boot[::5] = 0.0                                                # episodes that ended: value_estimate = 0
+    got = A.nstep_returns(rew, boot, 0.9)
+    assert torch.equal(got, nstep_returns(rew, boot, 0.9))         # same float32 operations in the same order
+
+
 def _twin_runners(torch, n_envs, T, **kw):
     from drl_uav_cellularnet_amd import BatchedMobiEnv
     from drl_uav_cellularnet_amd.agent import A2CRunner
