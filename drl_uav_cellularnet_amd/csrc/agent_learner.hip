@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void nstep_returns_kernel(const float *__restr
     if (n >= N) return;
     float run = boot[n];
     for (int t = T - 1; t >= 0; --t) {
-        run = rew[(long long)t * N + n] + gamma * run;
+        run = __fadd_rn(rew[(long long)t * N + n], __fmul_rn(gamma, run));   // two roundings, like the PyTorch form (no FMA contraction)
         out[(long long)t * N + n] = run;
     }
 }
