@@ -495,7 +495,8 @@ __global__ __launch_bounds__(256) void nstep_returns_kernel(const float *__restr
     if (n >= N) return;
     float run = boot[n];
     for (int t = T - 1; t >= 0; --t) {
-        run = __fadd_rn(rew[(long long)t * N + n], __fmul_rn(gamma, run));   // two roundings, like the PyTorch form (no FMA contraction)
+#pragma clang fp contract(off)   // two roundings per step, like the PyTorch form r[t] + gamma * run (hipcc would contract it into an FMA)
+        run = rew[(long long)t * N + n] + gamma * run;
         out[(long long)t * N + n] = run;
     }
 }
