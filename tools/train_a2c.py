@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The training loop of the reference's a2c_single_thread.py (:107-137, 207-224) on the batched HIP env: `--workers` env instances play the
+reference's workers (4 there), all stepped together; episodes of MAXSTEP = 2000 steps in rollouts of `--rollout` steps, one synchronous
+update per rollout; at the end the two files the reference writes: Global_return.npy (the running episode return, :169-172) and the
+actor parameters (Global_A_PARA: here a named .npz, agent.save_actor_npz -- loadable by tools/run_eval.py without pickle).
+
+  python tools/train_a2c.py --out train/run1 [--workers 8192] [--episodes 2] [--rollout 50] [--first-state zeros]
+  python -m torch.distributed.run --nproc-per-node 8 tools/train_a2c.py ...     # one process per GPU, gradients all-reduced (RCCL)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="train/run")
+    ap.add_argument("--workers", type=int, default=8192, help="env instances per GPU")
+    ap.add_argument("--episodes", type=int, default=2)
+    ap.add_argument("--rollout", type=int, default=50)
+    ap.add_argument("--n-ue", type=int, default=40, help="the reference's scripts run 4 UAV x 40 UE on a 100 x 100 grid")
+    ap.add_argument("--grid", type=int, default=100)
+    ap.add_argument("--first-state", choices=("obs", "zeros"), default="zeros")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner, save_actor_npz
+    from drl_uav_cellularnet_amd.sharding import shard_for_rank
+
+    base, _ = shard_for_rank(rank, world, a.workers)
+    env = BatchedMobiEnv(a.workers, nBS=4, nUE=a.n_ue, grid_n=a.grid, device=dev, env_id_base=base)
+    runner = A2CRunner(env, rollout=a.rollout, first_state=a.first_state)
+    per_episode = int(env.cfg.max_step) // a.rollout                       # a2c_single_thread.py:108
+    returns, t0 = [], time.time()
+    for ep in range(a.episodes):
+        for r in range(per_episode):
+            st = runner.train_rollout()
+        returns.append(runner.running_r)                                   # GLOBAL_RUNNING_R, :169-172
+        if rank == 0:
+            print(json.dumps({"episode": ep, "running_return": runner.running_r, "a_loss": st["a_loss"], "c_loss": st["c_loss"],
+                              "mean_reward": st["mean_reward"], "env_steps": (ep + 1) * per_episode * a.rollout * a.workers * world,
+                              "seconds": time.time() - t0}), flush=True)
+    if rank == 0:
+        os.makedirs(a.out, exist_ok=True)
+        np.save(os.path.join(a.out, "Global_return"), np.array([x for x in returns if x is not None], dtype=np.float64))   # :135
+        save_actor_npz(runner.net, os.path.join(a.out, "Global_A_PARA.npz"))                                             # :136
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
