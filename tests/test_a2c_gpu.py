@@ -37,3 +37,28 @@ def test_a2c_rollouts_and_updates_on_the_hip_env():
     assert steps == [10, 20, 0, 10]
     assert runner.running_r is not None        # an episode finished: GLOBAL_RUNNING_R bookkeeping ran
     assert not torch.equal(w0, runner.net.a_w3.detach())
+
+
+def test_training_tool_writes_the_reference_artifacts(tmp_path):
+    """tools/train_a2c.py = the loop of a2c_single_thread.py:107-137: one episode, then Global_return.npy + the actor parameters,
+    which tools/run_eval.py's loader accepts."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tmp_path, "run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "train_a2c.py"), "--out", out, "--workers", "96", "--episodes", "1",
+                        "--rollout", "100"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ret = np.load(os.path.join(out, "Global_return.npy"))
+    assert ret.shape == (1,) and np.isfinite(ret).all()                    # one finished episode -> one running-return entry
+    from drl_uav_cellularnet_amd.agent import ACNet, load_actor_npz
+
+    net = load_actor_npz(ACNet(50000, 625), os.path.join(out, "Global_A_PARA.npz"))
+    assert all(bool(torch.isfinite(q).all()) for q in net.actor_params())
