@@ -62,6 +62,16 @@ UAVENV_HD void lm_pin(double &v) {
 #endif
 }
 
+// The scalar-register counterpart: the value stays in an SGPR pair (a VOP3 float64 FMA may read ONE scalar operand, which is all a
+// Horner step fma(p, r, c_k) needs), so a coefficient costs neither a VGPR pair nor the two v_mov per use that an unpinned literal does.
+UAVENV_HD void lm_pin_sgpr(double &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(v));
+#else
+    (void)v;
+#endif
+}
+
 template <bool PIN>
 UAVENV_HD LeanCoef lm_make_coef() {
     LeanCoef c = {

@@ -1000,6 +1000,13 @@ __device__ __forceinline__ int tail_items(int U, int B) {
     return (R > 0 && (HB & (HB - 1)) == 0 && HB >= 2 && R * HB <= 64) ? HB : 0;
 }
 
+#ifndef UAVENV_MP_VGPR_PTRS
+#define UAVENV_MP_VGPR_PTRS 1   // build knob (A/B runs), see env_kernel_multipass
+#endif
+template <class T> __device__ __forceinline__ T *vgpr_ptr(T *q) { asm volatile("" : "+v"(q)); return q; }
+#ifndef UAVENV_MP_SGPR_COEF
+#define UAVENV_MP_SGPR_COEF 2   // build knob (A/B runs): 0 none, 1 = exp2 coefficients pinned in SGPRs, 2 = + sincospi, 3 = + log
+#endif
 #ifndef UAVENV_MP_WAVES
 #define UAVENV_MP_WAVES 3     // occupancy the register allocator must allow (waves per SIMD): 3 -> <= 168 VGPRs, 4 -> <= 128
 #endif
@@ -1020,7 +1027,23 @@ void env_kernel_multipass(const KParams p) {
     // 154.5 us; serving the 38 polynomial coefficients of the fading loop from LDS (one broadcast ds_read per use, -11 % VALU in
     // that loop, 167 VGPRs): 154.0 vs 154.1 us -- the LDS round trips it adds to each wave's dependency chain cost what the
     // moves did; forcing 4 wavefronts per SIMD (128 VGPRs, 28 scratch spills): 152.9 us.  None is worth its complexity.
-    const LeanCoef C = lm_make_coef<false>();
+    // Polynomial coefficients in SGPR PAIRS (lm_pin_sgpr): a float64 literal cannot be an operand, so every use of an unpinned
+    // coefficient costs a v_mov_b64 (50 of the 300 instructions of a fading iteration); VGPR pinning costs occupancy (above); a Horner
+    // step fma(p, r, c_k) may read one scalar operand, so SGPR-resident coefficients cost nothing per use.  The scalar file only has room
+    // once the pass loop's seven pointers live in VGPRs (UAVENV_MP_VGPR_PTRS).  One box, 8192 envs of 16 x 200
+    // (profiles/r02c_config5_multipass_v2.txt): none 150.5 us; exp2 146.4; exp2 + pointers 145.0; exp2 + sincospi + pointers 142.3
+    // (shipped); + log coefficients 146.8 (the scalar file overflows again).
+    LeanCoef C = lm_make_coef<false>();
+#if UAVENV_MP_SGPR_COEF >= 1
+    for (int k = 0; k < 13; ++k) lm_pin_sgpr(C.e2[k]);     // exp2: evaluated twice per fading iteration
+#endif
+#if UAVENV_MP_SGPR_COEF >= 2
+    for (int k = 0; k < 8; ++k) { lm_pin_sgpr(C.sp[k]); lm_pin_sgpr(C.cp[k]); }
+#endif
+#if UAVENV_MP_SGPR_COEF >= 3
+    for (int k = 0; k < 7; ++k) lm_pin_sgpr(C.lg[k]);
+    lm_pin_sgpr(C.ln2_hi); lm_pin_sgpr(C.ln2_lo);
+#endif
     const HotConst H = make_hot<false>(p);
 
     const int U = p.U, B = uav_count<BT, FAST>(p.B), Gr = p.Gr;
@@ -1077,6 +1100,25 @@ void env_kernel_multipass(const KParams p) {
     const int depth = erec.fifo_depth, step_n = erec.step_n;
     double sum_cur = 0.0;
     int n_outage = 0;
+#if UAVENV_MP_VGPR_PTRS
+    // The pointers the pass loop uses, as (uniform) VGPR pairs: 14 SGPRs fewer live across the fading loop, where the scalar
+    // file is wanted for polynomial coefficients (UAVENV_MP_SGPR_COEF); an access then forms its address with one v_lshl_add_u64.
+    UeAux *const pv_aux = vgpr_ptr(st.ue_aux);
+    UePos *const pv_pos = vgpr_ptr(st.ue_pos);
+    unsigned long long *const pv_bits = vgpr_ptr(st.out_bits);
+    const int8_t *const pv_gid = vgpr_ptr(p.gid_of_u);
+    int16_t *const pv_oxy = vgpr_ptr(p.out.ue_xy);
+    int8_t *const pv_osrv = vgpr_ptr(p.out.serving);
+    float *const pv_osinr = vgpr_ptr(p.out.cur_sinr);
+#else
+    UeAux *const pv_aux = st.ue_aux;
+    UePos *const pv_pos = st.ue_pos;
+    unsigned long long *const pv_bits = st.out_bits;
+    const int8_t *const pv_gid = p.gid_of_u;
+    int16_t *const pv_oxy = p.out.ue_xy;
+    int8_t *const pv_osrv = p.out.serving;
+    float *const pv_osinr = p.out.cur_sinr;
+#endif
 
     for (int it = 0; it < n_ticks; ++it) {
         const bool aggregating = agg != 0;
@@ -1097,14 +1139,14 @@ void env_kernel_multipass(const KParams p) {
             const bool owner = act && (!item || hb == 0);                  // the lane that stores the walker's results
             const long long iu = e * U + (act ? u : 0);
             int ix = 0, iy = 0;
-            UeAux aux = st.ue_aux[iu];                                    // inactive lanes read walker 0 of the env and store nothing
+            UeAux aux = pv_aux[iu];                                    // inactive lanes read walker 0 of the env and store nothing
             U4 h0 = {0u, 0u, 0u, 0u}, h1 = {0u, 0u, 0u, 0u};
             if (has_mobility(MODE)) {
-                const int gid = p.gid_of_u[act ? u : 0];                   // table: RPGM group of walker u (ue_mobility.py:417-426)
+                const int gid = pv_gid[act ? u : 0];                   // table: RPGM group of walker u (ue_mobility.py:417-426)
                 const double gx = __shfl(ogx, gid, 64), gy = __shfl(ogy, gid, 64);
                 const double gv = __shfl(ogv, gid, 64), gc = __shfl(ogc, gid, 64), gs = __shfl(ogs, gid, 64);
                 double x = 0, y = 0, hu = aux.hu;
-                if (act) { const UePos q = st.ue_pos[iu]; x = q.x; y = q.y; }
+                if (act) { const UePos q = pv_pos[iu]; x = q.x; y = q.y; }
                 bool c[4];
                 walker_move(H, C, aggregating, hu, gx, gy, gv, gc, gs, MAXC, x, y, c);
                 c[0] = c[0] && act; c[1] = c[1] && act; c[2] = c[2] && act; c[3] = c[3] && act;
@@ -1127,13 +1169,13 @@ void env_kernel_multipass(const KParams p) {
                 }
                 ix = (int)x; iy = (int)y;
                 aux.hu = hu;
-                if (owner) st.ue_pos[iu] = UePos{x, y};
+                if (owner) pv_pos[iu] = UePos{x, y};
             } else if (act) {
                 ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
             }
             aux.ix = (int16_t)ix; aux.iy = (int16_t)iy;
-            if (MODE == MODE_WARMUP) { if (owner) st.ue_aux[iu] = aux; continue; }
-            if (owner && UAV_OUT(p.out.ue_xy)) reinterpret_cast<int *>(p.out.ue_xy)[iu] = (int)(uint16_t)ix | ((int)(uint16_t)iy << 16);
+            if (MODE == MODE_WARMUP) { if (owner) pv_aux[iu] = aux; continue; }
+            if (owner && UAV_OUT(p.out.ue_xy)) reinterpret_cast<int *>(pv_oxy)[iu] = (int)(uint16_t)ix | ((int)(uint16_t)iy << 16);
 
             // ---- received powers, best UAV, the two SINR values -------------------------------------------------
             int best, serving = aux.serving;
@@ -1219,12 +1261,12 @@ void env_kernel_multipass(const KParams p) {
                 const unsigned long long prev = __shfl(prev_w, pass, 64);
                 n_outage += __popcll(ob & ~prev);                              // :171-174 newly outaged
             }
-            if (lane == 0) st.out_bits[e * p.W64 + pass] = ob;
+            if (lane == 0) pv_bits[e * p.W64 + pass] = ob;
             if (owner) {
                 aux.serving = (int8_t)serving; aux.r0 = (int8_t)r0; aux.r1 = (int8_t)r1; aux.r2 = (int8_t)r2;
-                st.ue_aux[iu] = aux;
-                if (UAV_OUT(p.out.serving)) p.out.serving[iu] = (int8_t)serving;
-                if (UAV_OUT(p.out.cur_sinr)) p.out.cur_sinr[iu] = (float)cur;
+                pv_aux[iu] = aux;
+                if (UAV_OUT(p.out.serving)) pv_osrv[iu] = (int8_t)serving;
+                if (UAV_OUT(p.out.cur_sinr)) pv_osinr[iu] = (float)cur;
                 if (UAV_OUT64(p.out.cur_sinr_f64)) p.out.cur_sinr_f64[iu] = cur;
             }
             sum_cur += wave_sum(owner ? cur : 0.0);
