@@ -139,6 +139,9 @@ template <bool LOCAL> __device__ __forceinline__ uint32_t block_local(uint32_t i
     return idx;
 }
 
+// A (wave-uniform) pointer kept in a VGPR pair: frees two SGPRs where the scalar file is the scarce resource.
+template <class T> __device__ __forceinline__ T *vgpr_ptr(T *q) { asm volatile("" : "+v"(q)); return q; }
+
 __device__ __forceinline__ StatePtrs state_from_blob(char *b, long long N, int U, int B, int Gr) {
     const StateOffsets L = compute_layout(N, U, B, Gr);
     StatePtrs s;
@@ -1003,7 +1006,6 @@ __device__ __forceinline__ int tail_items(int U, int B) {
 #ifndef UAVENV_MP_VGPR_PTRS
 #define UAVENV_MP_VGPR_PTRS 1   // build knob (A/B runs), see env_kernel_multipass
 #endif
-template <class T> __device__ __forceinline__ T *vgpr_ptr(T *q) { asm volatile("" : "+v"(q)); return q; }
 #ifndef UAVENV_MP_SGPR_COEF
 #define UAVENV_MP_SGPR_COEF 2   // build knob (A/B runs): 0 none, 1 = exp2 coefficients pinned in SGPRs, 2 = + sincospi, 3 = + log
 #endif
