@@ -327,6 +327,9 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     // 8.67 vs 9.20, 2.0 9.29 vs 9.77, 2.67 12.87 vs 12.08, 4.0 15.87 vs 14.98: two co-resident waves profit from constants that
     // are not re-read through the scalar path; a lone wave only pays for materialising them; beyond two, occupancy wins.
     bool pin = fast && (waves >= h->n_simd) && (waves <= 2 * h->n_simd);
+    // Multi-step launches: the pinned loop wins below one wavefront per SIMD too (1536 envs: 3.47 us per step unpinned; the lone-wave
+    // argument above is about materialising constants once per LAUNCH, which a 100-step launch amortises).
+    if (MANY) pin = fast && (waves <= 2 * h->n_simd);
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
