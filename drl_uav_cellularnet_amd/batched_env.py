@@ -95,6 +95,7 @@ class BatchedMobiEnv:
         self._lay = _capi.UavEnvStateLayout()
         _capi.check(self._lib.uavenv_state_layout(self._h, C.byref(self._lay)))
         self._keep = None
+        self._many_structs = {}          # step_many: id(out dict) -> (dict, byref(UavEnvOut), T, struct)
         self._constructed = False
         if construct:
             self.construct()
@@ -266,13 +267,20 @@ class BatchedMobiEnv:
         T = int(a.shape[0])
         if out is None:
             out = {k: torch.empty((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) for k, v in self.out.items()}
-        elif set(out) != set(self.out) or any(out[k].shape != (T,) + tuple(v.shape) or not out[k].is_contiguous()
-                                               for k, v in self.out.items()):
-            raise ValueError("out must be a dict returned by step_many for the same number of steps")
-        st = _capi.UavEnvOut()
-        for k, v in out.items():
-            setattr(st, k + "_dev", v.data_ptr())
-        _capi.check(self._lib.uavenv_step_many(self._h, a.data_ptr(), T, C.byref(st), self._stream()))
+        cached = self._many_structs.get(id(out))
+        if cached is None or cached[0] is not out or cached[2] != T:       # validate and build the pointer struct once per dict
+            if set(out) != set(self.out) or any(out[k].shape != (T,) + tuple(v.shape) or not out[k].is_contiguous()
+                                                for k, v in self.out.items()):
+                raise ValueError("out must be a dict returned by step_many for the same number of steps")
+            st = _capi.UavEnvOut()
+            for k, v in out.items():
+                setattr(st, k + "_dev", v.data_ptr())
+            if len(self._many_structs) > 16:
+                self._many_structs.clear()
+            cached = self._many_structs[id(out)] = (out, C.byref(st), T, st)
+        rc = self._lib.uavenv_step_many(self._h, a.data_ptr(), T, cached[1], self._stream())
+        if rc:
+            _capi.check(rc)
         if T > 0 and refresh_out:                        # (refresh_out=False: self.out goes stale until the next step()/reset())
             for k, v in self.out.items():
                 v.copy_(out[k][T - 1])
