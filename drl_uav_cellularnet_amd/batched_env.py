@@ -252,6 +252,14 @@ class BatchedMobiEnv:
         return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
                                                              "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
 
+    def out_struct_for(self, out):
+        """A UavEnvOut whose members point at the tensors of ``out`` (a dict with this env's output names): for callers that bind
+        uavenv_step_many / uavenv_step_seq themselves.  The caller keeps both alive."""
+        st = _capi.UavEnvOut()
+        for k in self.out:
+            setattr(st, k + "_dev", out[k].data_ptr())
+        return st
+
     def step_many(self, actions, out=None, refresh_out=True):
         """T consecutive step() calls in ONE launch (uavenv_step_many) for actions that do not depend on the observations in
         between: ``actions`` int64 [T, N] on this device.  Returns a dict of [T, ...] tensors (block t = what step t returned;
