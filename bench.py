@@ -377,6 +377,10 @@ def timed(fn, dist, dev):
     """synchronize + barrier, clock, K steps, synchronize, clock, barrier; HIP events on the launch stream inside -> (wall s, gpu ms)."""
     import torch
 
+    import gc
+
+    gc.collect()
+    gc.disable()                                # no collector pause inside a region that may last 0.1 ms
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -387,6 +391,7 @@ def timed(fn, dist, dev):
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0      # this rank's K steps are complete; the slowest rank's time is what is reported (MAX)
+    gc.enable()
     if dist is not None:
         dist.barrier()                      # closing bracket: nobody leaves before everybody has finished (not part of any rank's clock:
     return elapsed, ev0.elapsed_time(ev1)   # an RCCL barrier costs tens of microseconds, a 20-step region lasts 0.1 ms)
@@ -554,6 +559,10 @@ def main(argv=None):
             a2c = measure_a2c(args, dist, dev, reduce_dev, rank, world, A2C_ENVS, args.a2c_rollouts)
         except Exception as ex:                        # the headline line must survive a failure of the appended measurement
             a2c = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()                           # the A2C leg's buffers (several GB) go back to the driver before the env legs
     alt = {}
     if not args.no_alt and world == 1:                 # secondary: the other launch forms on the same box, same K / W
         for other in ("eager", "many", "graph", "seq"):
