@@ -379,8 +379,8 @@ def timed(fn, dist, dev):
 
     import gc
 
-    gc.collect()
-    gc.disable()                                # no collector pause inside a region that may last 0.1 ms
+    gc.disable()                                # no collector pause inside a region that may last 0.1 ms (and no gc.collect() here:
+                                                # tens of ms of host work would let the device idle and clock down before the region)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
