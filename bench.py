@@ -551,10 +551,9 @@ def main(argv=None):
         return BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=GRID, groups=groups, device=dev, seed=SEED, env_id_base=env_id_base)
 
     # Order: the other launch forms first (they bring clocks and caches up), then the headline behind its own scratch-env
-    # pre-warm, and the A2C leg LAST: measured on one box, a 20-step headline region placed after the A2C leg (TunableOp, rocBLAS /
-    # hipBLASLt handles, a captured graph, a side stream and several GB of buffers in the process) ran at 4.0-4.5e8 env-steps/s
-    # against 6.4-6.7e8 before it -- launch and synchronise latencies grow with what the process has created.  Every measurement
-    # has its own env, its own W warm-up steps and its own bracketed timed region.
+    # pre-warm, and the A2C leg LAST: measured on one box, a 20-step headline region ran at 5.6e8 env-steps/s when the A2C leg
+    # (TunableOp, BLAS handles, a captured graph, a side stream, several GB of buffers) came before it and at 6.5-6.7e8 when it
+    # comes after.  Every measurement has its own env, its own W warm-up steps and its own bracketed timed region.
     alt = {}
     if not args.no_alt and world == 1:                 # secondary: the other launch forms on the same box, same K / W
         for other in ("eager", "many", "graph", "seq"):
