@@ -80,3 +80,39 @@ def test_two_ranks_on_one_gpu_run_the_env_workload():
     line = _last_json(p.stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 40 and line["launch"] == "many"
     assert line["value"] > 0 and line["config"]["parallelism"] == "env-shard x2"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launch", ["many", "seq", "graph", "eager"])
+def test_precompiled_timed_region_steps_the_env_like_run(launch):
+    """bench.EnvRun.compile (the list of bound calls the timed region executes) advances the env exactly like EnvRun.run and like
+    plain step() calls on the same action rows: the benchmark times real steps, in every launch form."""
+    import numpy as np
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+
+    env = BatchedMobiEnv(300, nBS=4, nUE=20, grid_n=100, max_step=130)
+    ref = env.clone()
+    pool = torch.randint(0, 625, (400, 300), generator=torch.Generator().manual_seed(5), dtype=torch.int64).to(env.device)
+    r = bench.EnvRun(env, launch, pool)
+    W, K = 30, 170                                                    # crosses a reset (MAXSTEP 130) and several chunk borders
+    r.prepare([n for n, _ in r.plan(W)] + [n for n, _ in r.plan(K, t0=(r.t + W) % r.max_step)])
+    r.run(W)
+    r.stage(K)
+    for f in r.compile(K):
+        f()
+    t = 0
+    for i in range(W + K):
+        ref.step(pool[i])
+        t += 1
+        if t == 130:
+            ref.reset()
+            t = 0
+    torch.cuda.synchronize()
+    assert np.array_equal(env.get_state(), ref.get_state())
+    assert r.t == t
