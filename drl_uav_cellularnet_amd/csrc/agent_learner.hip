@@ -66,26 +66,16 @@ template <int PER>
 __global__ __launch_bounds__(256) void sample_actions_kernel(const float *__restrict__ logits, const float *__restrict__ uni,
                                                              long long N, int A, long long *__restrict__ action,
                                                              float *__restrict__ prob) {
-    // The row comes in through LDS: global loads are coalesced (lane l reads columns l, l + 64, ...: 64 consecutive floats per
-    // instruction), then every lane picks up its PER CONSECUTIVE columns, which is what the running sum needs.  (Reading them
-    // straight from global memory made each load instruction span 64 * PER * 4 bytes for 256 useful ones.)
-    __shared__ float s_row[4][PER * 64];
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const long long r = (long long)blockIdx.x * 4 + w;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
     const float *row = logits + r * A;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int c = k * 64 + lane;
-        s_row[w][c] = (c < A) ? row[c] : -3.0e38f;
-    }
-    __builtin_amdgcn_wave_barrier();            // (a wavefront only reads what it wrote itself)
     float v[PER];
     float mx = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        v[k] = s_row[w][lane * PER + k];
+        const int c = lane * PER + k;
+        v[k] = (c < A) ? row[c] : -3.0e38f;
         mx = fmaxf(mx, v[k]);
     }
     mx = wave_max_f(mx);
