@@ -328,6 +328,7 @@ class A2CRunner:
             self.idx_buf[T].fill_(-1)
         self.ep_r = torch.zeros(N, device=self.dev)
         self.running_r = None                                          # GLOBAL_RUNNING_R EMA, :169-172
+        self.last_episode_return = None
         self.stats = {}
         self._graph = None
         self._upd = None
@@ -399,6 +400,7 @@ class A2CRunner:
         boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
         if bool(done.any()):                                                         # :167-172 reset_worker
             m = float(self.ep_r[done].mean())
+            self.last_episode_return = m                                             # mean return of the episodes that just ended
             self.running_r = m if self.running_r is None else 0.99 * self.running_r + 0.01 * m
             self.ep_r[done] = 0.0
             env.reset(mask=done)

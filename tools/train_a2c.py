@@ -50,7 +50,8 @@ def main():
             st = runner.train_rollout()
         returns.append(runner.running_r)                                   # GLOBAL_RUNNING_R, :169-172
         if rank == 0:
-            print(json.dumps({"episode": ep, "running_return": runner.running_r, "a_loss": st["a_loss"], "c_loss": st["c_loss"],
+            print(json.dumps({"episode": ep, "episode_return": runner.last_episode_return, "running_return": runner.running_r,
+                              "a_loss": st["a_loss"], "c_loss": st["c_loss"],
                               "mean_reward": st["mean_reward"], "env_steps": (ep + 1) * per_episode * a.rollout * a.workers * world,
                               "seconds": time.time() - t0}), flush=True)
     if rank == 0:
