@@ -37,6 +37,16 @@ def test_one_command_starts_and_counts_two_ranks():
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1         # ONE line, from rank 0
 
 
+def test_external_launcher_two_ranks():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N (RANK / WORLD_SIZE from the launcher)."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", BENCH, "--gpus", "2", "--rehearse-launcher"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["n_gpus"] == 2 and line["launcher"] == "external" and line["max_env_id_base"] == 4096.0
+
+
 def test_wrong_rank_count_is_refused_not_reported():
     """Under an external launcher WORLD_SIZE is authoritative: --gpus 2 inside a 1-rank job must exit non-zero, never print an
     `n_gpus: 1` line (round 1 did exactly that)."""
