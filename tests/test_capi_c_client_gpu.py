@@ -45,3 +45,26 @@ def test_c_client_matches_the_python_binding(tmp_path):
         assert int(r[1]) == g[0] and int(r[3]) == g[2] and int(r[4]) == g[3] and int(r[5]) == g[4], (r, g)
         np.testing.assert_allclose(float(r[2]), g[1], rtol=1e-6)              # (float32 rewards summed in double on both sides)
     assert [g[0] for g in got] == [1, 2, 3, 4, 5, 6, 7, 8]
+
+
+def test_integration_md_ctypes_stub_runs():
+    """The stand-alone ctypes binding printed in INTEGRATION.md section 2(b) is executed verbatim: documentation that runs."""
+    import re
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "lib.uavenv_create" in b]
+    assert len(stub) == 1
+    cwd = os.getcwd()
+    os.chdir(ROOT)                                   # the stub loads the library by its in-tree relative path
+    try:
+        ns = {}
+        exec(compile(stub[0], "INTEGRATION.md:2b", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    assert int(ns["bufs"]["step_n"].min()) == 1 and bool(torch.isfinite(ns["bufs"]["reward"]).all())
