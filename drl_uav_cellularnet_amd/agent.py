@@ -283,8 +283,7 @@ class A2CRunner:
     around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=True,
-                 side_stream_critic=True):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -333,8 +332,6 @@ class A2CRunner:
         self.stats = {}
         self._graph = None
         self._upd = None
-        self._side = None
-        self.side_stream_critic = bool(side_stream_critic)
 
     def _ms_view(self, key):
         p = getattr(self.net, key)
@@ -364,25 +361,10 @@ class A2CRunner:
         if cuda:
             from . import _agent_capi as A
         fw = self._fwd
-        main = side = None
-        if cuda and self.side_stream_critic:
-            # The critic's first layer of step t is needed by the UPDATE only, so it runs on a side stream behind the event "idx_buf[t]
-            # is written" and overlaps the actor's GEMMs, the sampling and the env kernel of the main stream (a 20 us row gather
-            # bound by cache latency beside compute-bound kernels); joined once, after the last step.  Captured like everything else.
-            main = torch.cuda.current_stream(self.dev)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.dev)
-            side = self._side
         for t in range(T):
-            if cuda and side is not None:
-                side.wait_stream(main)                                           # idx_buf[t] (and the weights) are ready
-                with torch.cuda.stream(side):
-                    A.sparse_rows_sum(self.idx_buf[t], net.c_w1, net.c_b1, relu6=True, out_a=fw["h1c"][t])
-                A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, relu6=True, out_a=fw["h1a"][t])
-            elif cuda:
+            if cuda:
                 A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
                                   out_c=fw["h1c"][t])
-            if cuda:
                 torch.addmm(net.a_b2, fw["h1a"][t], net.a_w2, out=fw["h2a"][t]).clamp_(0.0, 6.0)
                 torch.addmm(net.a_b3, fw["h2a"][t], net.a_w3, out=fw["logits"][t])
                 A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
@@ -391,8 +373,6 @@ class A2CRunner:
                 self.act_buf[t] = sample_actions(prob, uniforms=self.u_buf[t])
             env.step(self.act_buf[t], reward_out=self.rew_buf[t])
             self._indices_into(self.idx_buf[t + 1])
-        if side is not None:
-            main.wait_stream(side)
 
     @torch.no_grad()
     def collect(self):
