@@ -555,11 +555,11 @@ def main(argv=None):
     # (TunableOp, BLAS handles, a captured graph, a side stream, several GB of buffers) came before it and at 6.5-6.7e8 when it
     # comes after.  Every measurement has its own env, its own W warm-up steps and its own bracketed timed region.
     alt = {}
-    if not args.no_alt and world == 1:                 # secondary: the other launch forms on the same box, same K / W
-        for other in ("eager", "many", "graph", "seq"):
+    if not args.no_alt:                                # secondary: the other launch forms on the same box, same K / W
+        for other in (("eager", "many", "graph", "seq") if world == 1 else ("seq",)):   # N > 1: the one-kernel-per-step form only
             if other != args.launch:
                 el, gm = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
-                alt[other] = {"value": E * K / el, "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
+                alt[other] = {"value": whole_job_rate(E * K, world, el), "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
                               "us_per_step_gpu": gm * 1e3 / K}
     elapsed, gpu_ms = measure_env(args, make_env(), args.launch, K, W, dist, dev, reduce_dev, rank, scratch=make_env())
     a2c = None
