@@ -555,6 +555,35 @@ class A2CRunner:
     def train_rollout(self):
         return self.update(*self.collect())
 
+    # ---- checkpoint / resume (the reference saves the actor only and cannot resume) -------------------------------
+    def state_dict(self):
+        """Everything a bit-identical continuation needs: both trunks and their RMSProp accumulators (the flat buffers), the env batch
+        (state blob + last outputs), the current observation indices, the episode bookkeeping and the action-sampling generator."""
+        env = self.env
+        blob = torch.empty(env._lay.total_bytes, dtype=torch.uint8, device=self.dev)
+        env.copy_state_to(blob)
+        return {"format": 1, "n_envs": env.n_envs, "n_bs": env.nBS, "n_ue": env.nUE, "grid_n": env.grid_n, "rollout": self.T,
+                "w": self.flat.w.detach().cpu(), "ms": self.flat.ms.detach().cpu(), "env_state": blob.cpu(), "env_out": env._arena.cpu(),
+                "idx": self.idx_buf[self.T].cpu(), "ep_r": self.ep_r.cpu(), "running_r": self.running_r,
+                "last_episode_return": self.last_episode_return, "gen_state": self.gen.get_state().cpu()}
+
+    def load_state_dict(self, sd):
+        env = self.env
+        shape = (sd["n_envs"], sd["n_bs"], sd["n_ue"], sd["grid_n"], sd["rollout"])
+        if sd.get("format") != 1 or shape != (env.n_envs, env.nBS, env.nUE, env.grid_n, self.T):
+            raise ValueError("checkpoint was written for another configuration: %r" % (shape,))
+        with torch.no_grad():
+            self.flat.w.copy_(sd["w"])
+            self.flat.ms.copy_(sd["ms"])
+            env.copy_state_from(sd["env_state"].to(self.dev))
+            env._arena.copy_(sd["env_out"])
+            self.idx_buf[self.T].copy_(sd["idx"])
+            self.ep_r.copy_(sd["ep_r"])
+        self.running_r, self.last_episode_return = sd["running_r"], sd["last_episode_return"]
+        self.gen.set_state(sd["gen_state"].cpu())
+        self._fwd_valid = False
+        torch.cuda.synchronize(self.dev) if self.dev.type == "cuda" else None
+
 
 ACTOR_KEYS = ("a_w1", "a_b1", "a_w2", "a_b2", "a_w3", "a_b3")   # TF order: la/kernel, la/bias, la2/kernel, la2/bias, ap/kernel, ap/bias
 

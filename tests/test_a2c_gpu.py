@@ -62,3 +62,36 @@ def test_training_tool_writes_the_reference_artifacts(tmp_path):
 
     net = load_actor_npz(ACNet(50000, 625), os.path.join(out, "Global_A_PARA.npz"))
     assert all(bool(torch.isfinite(q).all()) for q in net.actor_params())
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """A2CRunner.state_dict / load_state_dict ("Checkpoint / resume": the reference saves the actor only): a run
+    restored from a checkpoint continues exactly like the uninterrupted one -- weights, RMSProp accumulators, env batch, episode
+    bookkeeping and the sampling generator all come back (every kernel on the path is deterministic)."""
+    import os
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner
+
+    def fresh():
+        env = BatchedMobiEnv(256, nBS=4, nUE=20, grid_n=100, max_step=12)       # episodes end inside the third rollout
+        return A2CRunner(env, rollout=5)
+
+    a = fresh()
+    for _ in range(3):
+        a.train_rollout()
+    path = os.path.join(tmp_path, "ckpt.pt")
+    torch.save(a.state_dict(), path)
+    for _ in range(3):
+        sa = a.train_rollout()
+    b = fresh()
+    b.load_state_dict(torch.load(path, weights_only=True))
+    for _ in range(3):
+        sb = b.train_rollout()
+    assert torch.equal(a.flat.w, b.flat.w) and torch.equal(a.flat.ms, b.flat.ms)
+    assert np.array_equal(a.env.get_state(), b.env.get_state()) and torch.equal(a.idx, b.idx)
+    assert sa["a_loss"] == sb["a_loss"] and a.running_r == b.running_r and torch.equal(a.ep_r, b.ep_r)

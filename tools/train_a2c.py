@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--n-ue", type=int, default=40, help="the reference's scripts run 4 UAV x 40 UE on a 100 x 100 grid")
     ap.add_argument("--grid", type=int, default=100)
     ap.add_argument("--first-state", choices=("obs", "zeros"), default="zeros")
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="episodes between full checkpoints (<out>/checkpoint_rank<r>.pt); 0 = never")
+    ap.add_argument("--resume", action="store_true", help="continue from <out>/checkpoint_rank<r>.pt (bit-identical to an uninterrupted run)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -44,8 +46,13 @@ def main():
     env = BatchedMobiEnv(a.workers, nBS=4, nUE=a.n_ue, grid_n=a.grid, device=dev, env_id_base=base)
     runner = A2CRunner(env, rollout=a.rollout, first_state=a.first_state)
     per_episode = int(env.cfg.max_step) // a.rollout                       # a2c_single_thread.py:108
-    returns, t0 = [], time.time()
-    for ep in range(a.episodes):
+    returns, t0, first_ep = [], time.time(), 0
+    ckpt = os.path.join(a.out, "checkpoint_rank%d.pt" % rank)
+    if a.resume:
+        sd = torch.load(ckpt, weights_only=True)                           # (a file this tool wrote: tensors and plain scalars only)
+        runner.load_state_dict(sd["runner"])
+        first_ep, returns = int(sd["episode"]) + 1, list(sd["returns"])
+    for ep in range(first_ep, a.episodes):
         for r in range(per_episode):
             st = runner.train_rollout()
         returns.append(runner.running_r)                                   # GLOBAL_RUNNING_R, :169-172
@@ -54,6 +61,9 @@ def main():
                               "a_loss": st["a_loss"], "c_loss": st["c_loss"],
                               "mean_reward": st["mean_reward"], "env_steps": (ep + 1) * per_episode * a.rollout * a.workers * world,
                               "seconds": time.time() - t0}), flush=True)
+        if a.checkpoint_every and (ep + 1) % a.checkpoint_every == 0:
+            os.makedirs(a.out, exist_ok=True)
+            torch.save({"runner": runner.state_dict(), "episode": ep, "returns": returns}, ckpt)
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
         np.save(os.path.join(a.out, "Global_return"), np.array([x for x in returns if x is not None], dtype=np.float64))   # :135
