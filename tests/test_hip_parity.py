@@ -152,6 +152,13 @@ PHILOX_SHAPES = [
     (4, 20, 8, 7, 40, {}),                     # the smallest grid (8 x 8): UAVs 4 cells apart, frozen by the distance rule
     (4, 4, 32, 40, 40, {}),                    # U == B == Gr: every lane of a slot is walker, group owner and UAV owner; 8 envs per wave (kMaxEpw caps 16)
     (8, 64, 100, 3, 12, {}),                   # packed, BT = 8 with B = 8 (FAST), full-wavefront slots
+    # quad draws (B > 8: one Philox call per four UAVs) away from the 16 x 200 shape, and BT = 32
+    (9, 20, 64, 6, 12, {}),                    # packed, BT = 16 checked (B = 9): the third call serves ONE UAV
+    (10, 70, 64, 4, 8, {}),                    # multi-pass, HB = 5 (not a power of two: plain tail pass), last call half used
+    (20, 200, 100, 2, 6, {}),                  # multi-pass, B = 20 in the BT-agnostic checked variant, HB = 10, 5^20 actions
+    (32, 64, 100, 3, 6, {"n_act": 2}),         # packed, BT = 32 FAST (2^32 joint actions), full-wavefront slots
+    (32, 200, 100, 2, 4, {"n_act": 2}),        # multi-pass FAST, HB = 16: 8 tail walkers x 16 lanes > 64 -> plain tail
+    (32, 66, 100, 3, 6, {"n_act": 2}),         # multi-pass FAST, 2 tail walkers x 16 lanes: item-layout tail with 16-lane groups
 ]
 
 
@@ -382,7 +389,8 @@ def _full(env):
     return twin.dense_obs()
 
 
-@pytest.mark.parametrize("shape", [(4, 20, 100, 200), (4, 40, 100, 64), (8, 24, 64, 48), (16, 32, 100, 24)],
+@pytest.mark.parametrize("shape", [(4, 20, 100, 200), (4, 40, 100, 64), (8, 24, 64, 48), (16, 32, 100, 24),
+                                   (16, 200, 100, 6), (4, 200, 100, 6), (32, 64, 100, 6, 2), (32, 66, 100, 4, 2)],   # + multi-pass FAST, BT = 32
                          ids=lambda s: "B%dU%dN%d" % (s[0], s[1], s[3]))
 @pytest.mark.parametrize("pin", ["1", "0"], ids=["pinned", "unpinned"])
 def test_production_fast_variant_matches_oracle(shape, pin, monkeypatch):
@@ -393,21 +401,24 @@ def test_production_fast_variant_matches_oracle(shape, pin, monkeypatch):
     from oracle import oracle as O
 
     monkeypatch.setenv("UAVENV_FORCE_PIN", pin)          # read by the launcher at every launch
-    B, U, G, N = shape
+    B, U, G, N = shape[:4]
+    n_act = shape[4] if len(shape) > 4 else 5                     # (5^B must fit int64: B = 32 runs with two actions per UAV)
+    over = {} if n_act == 5 else {"n_act": n_act}
+    groups = [U // 4] * 3 + [U - 3 * (U // 4)]
     side = int(np.ceil(np.sqrt(B)))
     bs_init = None if B == 4 else [(G // (2 * side) + (b // side) * (G // side), G // (2 * side) + (b % side) * (G // side))
                                    for b in range(B)]
-    env = _make(N, nBS=B, nUE=U, grid_n=G, bs_init=bs_init, seed=2024, env_id_base=5)   # f64_outputs=False -> FAST
+    env = _make(N, nBS=B, nUE=U, grid_n=G, groups=groups, bs_init=bs_init, seed=2024, env_id_base=5, **over)   # f64_outputs=False -> FAST
     assert "cur_sinr_f64" not in env.out
-    orc = O.OracleEnv(O.make_config(B, U, G, groups=[U // 4] * 4, bs_init=bs_init), N, seed=2024, env_id_base=5)
+    orc = O.OracleEnv(O.make_config(B, U, G, groups=groups, bs_init=bs_init, **over), N, seed=2024, env_id_base=5)
     oo = orc.construct()
     rs = np.random.RandomState(11)
     T = 48
     for t in range(T):
-        digits = rs.randint(0, 5, size=(N, B)).astype(np.int64)
+        digits = rs.randint(0, n_act, size=(N, B)).astype(np.int64)
         act = np.zeros(N, np.int64)
         for b in range(B):
-            act = act * 5 + digits[:, b]
+            act = act * n_act + digits[:, b]
         if t == T // 2:
             mask = (np.arange(N) % 3 == 1).astype(np.uint8)
             env.reset(mask=mask)
