@@ -42,7 +42,13 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
-ABI_VERSION = 3   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
+class UavEnvOutPacked(C.Structure):
+    _fields_ = [(n, _P) for n in ("walker_dev", "bs_xy_dev", "env_dev")]
+
+
+WALKER_OUT_BYTES, STEP_OUT_BYTES = 12, 16   # sizeof(UavEnvWalkerOut), sizeof(UavEnvStepOut)
+
+ABI_VERSION = 4   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
 STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
@@ -51,8 +57,9 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
-           "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_many_packed", "uavenv_unpack_outputs", "uavenv_step_seq", "uavenv_step_trace",
+           "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area", "uavenv_sinr_area_at",
+           "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
 
 _lib = None
@@ -92,10 +99,16 @@ def load():
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_seq.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step_many_packed.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOutPacked), _P]
+    lib.uavenv_unpack_outputs.argtypes = [_P, C.POINTER(UavEnvOutPacked), C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_obs_dense.argtypes = [_P, _P, _P]
     lib.uavenv_obs_dense_update.argtypes = [_P, _P, _P]
     lib.uavenv_sinr_area.argtypes = [_P, _P, _P, _P, _P]
+    lib.uavenv_sinr_area_at.argtypes = [_P, _P, _P, _P, _P, _P]
+    lib.uavenv_debug_variant_count.restype = C.c_int
+    lib.uavenv_debug_variant_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    lib.uavenv_debug_variant_reset.restype = None
     lib.uavenv_state_layout.argtypes = [_P, C.POINTER(UavEnvStateLayout)]
     lib.uavenv_get_state.argtypes = [_P, _P, C.c_int, _P]
     lib.uavenv_set_state.argtypes = [_P, _P, C.c_int, _P]
@@ -132,6 +145,18 @@ def make_config(n_bs, n_ue, grid, groups=None, bs_init=None, **over):
             raise AttributeError("UavEnvConfig has no field %r" % k)
         setattr(cfg, k, v)
     return cfg
+
+
+def launch_census():
+    """[(name, selectable, launches)] for every kernel instantiation slot (uavenv_debug_variant_info): test hook."""
+    lib = load()
+    out = []
+    buf = C.create_string_buffer(160)
+    for i in range(lib.uavenv_debug_variant_count()):
+        sel, n = C.c_int(), C.c_longlong()
+        check(lib.uavenv_debug_variant_info(i, buf, len(buf), C.byref(sel), C.byref(n)))
+        out.append((buf.value.decode(), bool(sel.value), int(n.value)))
+    return out
 
 
 def philox4x32_10(ctr, key):

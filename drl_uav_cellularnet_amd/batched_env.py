@@ -294,6 +294,54 @@ class BatchedMobiEnv:
                 v.copy_(out[k][T - 1])
         return out
 
+    # Record formats of the packed outputs (include/uavenv.h: UavEnvWalkerOut, UavEnvStepOut), for host-side decoding.
+    WALKER_OUT_DTYPE = np.dtype([("ix", "<i2"), ("iy", "<i2"), ("cur_sinr", "<f4"), ("serving", "i1"), ("pad", "i1", (3,))])
+    STEP_OUT_DTYPE = np.dtype([("reward", "<f4"), ("mean_sinr", "<f4"), ("step_n", "<i4"), ("n_out", "<i2"), ("done", "u1"), ("pad", "u1")])
+
+    def packed_out_struct(self, packed):
+        st = _capi.UavEnvOutPacked()
+        st.walker_dev, st.bs_xy_dev, st.env_dev = packed["walker"].data_ptr(), packed["bs_xy"].data_ptr(), packed["env"].data_ptr()
+        return st
+
+    def step_many_packed(self, actions, out=None):
+        """step_many with one RECORD per walker / env and step instead of nine arrays (uavenv_step_many_packed): returns
+        {"walker": uint8 [T, N, U, 12], "bs_xy": int32 [T, N, B, 2], "env": uint8 [T, N, 16]} (record layouts: WALKER_OUT_DTYPE,
+        STEP_OUT_DTYPE); ``unpack_outputs`` turns it into the nine [T, ...] arrays step_many returns, bit for bit.  The multi-step
+        kernel then advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.  ``self.out`` is NOT
+        refreshed (call unpack_outputs / step() before reading it)."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int64).contiguous()
+            self._act_keep = a
+        if a.dim() != 2 or a.shape[1] != self.n_envs:
+            raise ValueError("actions must be [T, n_envs]")
+        T, N, U, B = int(a.shape[0]), self.n_envs, self.nUE, self.nBS
+        shapes = {"walker": ((T, N, U, _capi.WALKER_OUT_BYTES), torch.uint8), "bs_xy": ((T, N, B, 2), torch.int32),
+                  "env": ((T, N, _capi.STEP_OUT_BYTES), torch.uint8)}
+        if out is None:
+            out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
+        elif set(out) != set(shapes) or any(tuple(out[k].shape) != sh or out[k].dtype != dt or not out[k].is_contiguous()
+                                            for k, (sh, dt) in shapes.items()):
+            raise ValueError("out must be a dict returned by step_many_packed for the same number of steps")
+        st = self.packed_out_struct(out)
+        rc = self._lib.uavenv_step_many_packed(self._h, a.data_ptr(), T, C.byref(st), self._stream())
+        if rc:
+            _capi.check(rc)
+        return out
+
+    def unpack_outputs(self, packed, out=None):
+        """Packed records of T steps -> the nine output arrays, [T, ...] each (uavenv_unpack_outputs)."""
+        T = int(packed["env"].shape[0])
+        if out is None:
+            out = {k: torch.empty((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) for k, v in self.out.items()
+                   if not k.endswith("_f64")}
+        st_in = self.packed_out_struct(packed)
+        st = _capi.UavEnvOut()
+        for k, v in out.items():
+            setattr(st, k + "_dev", v.data_ptr())
+        _capi.check(self._lib.uavenv_unpack_outputs(self._h, C.byref(st_in), T, C.byref(st), self._stream()))
+        return out
+
     def step_trace(self, actions, ue_xy, fading=None):
         """MobiEnvironment.step_test with mobility_model == 'read_trace' (mobile_env.py:196-233)."""
         a = self._actions(actions)
@@ -353,11 +401,19 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_obs_dense_update(self._h, buf.data_ptr(), self._stream()))
         return buf
 
-    def sinr_area(self, fading=None, dtype=torch.float32):
+    def sinr_area(self, fading=None, dtype=torch.float32, bs_xy=None):
         """LTEChannel.GetSinrInArea (channel.py:411-433) for every env: [N, G, G] dB, nearest-UAV SINR per cell with
-        fresh shadowing (row / column 0 are 0, as in the reference).  ``fading``: injected draws [N, (G-1)^2, B]."""
+        fresh shadowing (row / column 0 are 0, as in the reference).  ``fading``: injected draws [N, (G-1)^2, B].
+        ``bs_xy``: any UAV cells [N, B, 2] (the reference's ``bsLoc`` argument); default = the env's current cells."""
         N, B, G = self.n_envs, self.nBS, self.grid_n
         out = torch.empty((N, G, G), dtype=dtype, device=self.device)
+        bptr = None
+        if bs_xy is not None:
+            b = torch.as_tensor(bs_xy).to(device=self.device, dtype=torch.int32).contiguous()
+            if b.numel() != N * B * 2:
+                raise ValueError("bs_xy must be [n_envs, nBS, 2]")
+            self._bs_keep = b
+            bptr = b.data_ptr()
         fptr = None
         if fading is not None:
             f = self._dev64(fading, (N, (G - 1) * (G - 1), B))
@@ -367,7 +423,7 @@ class BatchedMobiEnv:
         o64 = out.data_ptr() if dtype == torch.float64 else None
         if o32 is None and o64 is None:
             raise ValueError("dtype must be torch.float32 or torch.float64")
-        _capi.check(self._lib.uavenv_sinr_area(self._h, fptr, o32, o64, self._stream()))
+        _capi.check(self._lib.uavenv_sinr_area_at(self._h, bptr, fptr, o32, o64, self._stream()))
         return out
 
     # ---- state blob: copy.deepcopy(env) (gradient.py:15) / checkpoint --------------------------------

@@ -2,6 +2,7 @@
 // gfx950 only; built by drl_uav_cellularnet_amd/build.py with hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,7 @@ struct uavenv {
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
     const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
+    char *scratch_out;  // multi-pass handles, uavenv_step_many_packed: one step's nine output arrays (allocated on first use)
     int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
@@ -261,6 +263,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->act_pow_dev);
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
+    if (h->scratch_out) (void)hipFree(h->scratch_out);
     delete h;
 }
 
@@ -297,8 +300,67 @@ static bool call_is_fast(const KParams &p) {
            o.bs_xy && o.serving && o.cur_sinr && o.step_n && !o.cur_sinr_f64 && !o.mean_sinr_f64 && !o.reward_f64;
 }
 
-template <int MODE, bool MANY = false>
+// ---- launch census (test hook, uavenv_debug_variant_*) --------------------------------------------------------------------------
+// Every launch of an env kernel is counted under the template instantiation that ran, and variant_selectable() states which
+// instantiations launch_env can choose at all.  tests/test_launch_variants_gpu.py drives every one of them against the oracle
+// and then asserts that none was left out: a kernel instantiation that ships has a parity test (the unpinned
+// multi-step kernel had quoted numbers and no test).  Key = (family, BT, MODE, PLC, variant, MANY).
+enum { FAM_PACKED = 0, FAM_MULTIPASS = 1 };
+enum { VAR_CHECKED = 0, VAR_FAST = 1, VAR_PIN = 2 };
+constexpr int kCensusSlots = 2 * 4 * 5 * 2 * 3 * 3;
+static std::atomic<long long> g_census[kCensusSlots];
+static constexpr int bt_index(int bt) { return bt == 4 ? 0 : bt == 8 ? 1 : bt == 16 ? 2 : 3; }
+static constexpr int census_index(int fam, int bt, int mode, bool plc, int var, int many) {   // many: 0 single step, 1 multi-step, 2 multi-step with packed output records
+    return ((((fam * 4 + bt_index(bt)) * 5 + mode) * 2 + (plc ? 1 : 0)) * 3 + var) * 3 + many;
+}
+// The image of launch_env's selection logic (keep the two in step: census_count() refuses a key this predicate rejects).
+static bool variant_selectable(int fam, int bt, int mode, bool plc, int var, int many) {
+    if (mode == MODE_WARMUP)                               // mobility only: one BT = 4, PLC instantiation per family, FAST or checked
+        return bt == 4 && plc && many == 0 && (var == VAR_CHECKED || var == VAR_FAST);
+    if (fam == FAM_PACKED) return many == 0 || mode == MODE_STEP;      // every (BT, PLC, variant); MANY / PKO exist for MODE_STEP only
+    if (many != 0 || var == VAR_PIN) return false;              // multi-pass: no PIN variant, uavenv_step_many loops over single steps
+    return var == VAR_FAST || bt == 4;                     // the checked multi-pass kernel reads B at run time: BT = 4 serves all
+}
+static bool census_count(int fam, int bt, int mode, bool plc, int var, int many) {
+    if (!variant_selectable(fam, bt, mode, plc, var, many)) return false;
+    g_census[census_index(fam, bt, mode, plc, var, many)].fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+static void census_decode(int i, int &fam, int &bt, int &mode, bool &plc, int &var, int &many) {
+    many = i % 3; i /= 3;
+    var = i % 3; i /= 3;
+    plc = i & 1; i >>= 1;
+    mode = i % 5; i /= 5;
+    static const int bts[4] = {4, 8, 16, 32};
+    bt = bts[i & 3]; fam = i >> 2;
+}
+extern "C" int uavenv_debug_variant_count(void) { return kCensusSlots; }
+extern "C" int uavenv_debug_variant_info(int i, char *name, size_t name_len, int *selectable, long long *launches) {
+    if (i < 0 || i >= kCensusSlots) return fail(UAVENV_E_INVALID, "debug_variant_info: index out of range");
+    int fam, bt, mode, var, many; bool plc;
+    census_decode(i, fam, bt, mode, plc, var, many);
+    static const char *modes[5] = {"WARMUP", "RESET", "STEP", "TRACE", "RESET_TRACE"};
+    if (name && name_len) {
+        if (fam == FAM_PACKED)
+            std::snprintf(name, name_len, "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d, PKO=%d>", bt, modes[mode], (int)plc,
+                          (int)(var != VAR_CHECKED), (int)(var == VAR_PIN), (int)(many != 0), (int)(many == 2));
+        else
+            std::snprintf(name, name_len, "env_kernel_multipass<BT=%d, %s, PLC=%d, FAST=%d>%s", bt, modes[mode], (int)plc,
+                          (int)(var != VAR_CHECKED), (var == VAR_PIN || many != 0) ? " (no such kernel)" : "");
+    }
+    if (selectable) *selectable = variant_selectable(fam, bt, mode, plc, var, many) ? 1 : 0;
+    if (launches) *launches = g_census[i].load(std::memory_order_relaxed);
+    return UAVENV_OK;
+}
+extern "C" void uavenv_debug_variant_reset(void) {
+    for (auto &c : g_census) c.store(0, std::memory_order_relaxed);
+}
+
+
+// MANY_: 0 = one step / reset / tick batch per launch, 1 = uavenv_step_many (nine output arrays), 2 = uavenv_step_many_packed
+template <int MODE, int MANY_ = 0>
 static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
+    constexpr bool MANY = MANY_ != 0, PKO = MANY_ == 2;
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
     const long long waves = (p.N + p.epw - 1) / p.epw;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -318,10 +380,13 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
             hipLaunchKernelGGL((env_kernel_multipass<4, MODE_WARMUP, true, false>), dim3(grid), blk, 0, s, p);
         }
         HIP_TRY(hipGetLastError());
+        if (!census_count(h->packed ? FAM_PACKED : FAM_MULTIPASS, 4, MODE_WARMUP, true, fast ? VAR_FAST : VAR_CHECKED, 0))
+            return fail(UAVENV_E_INVALID, "launch census: warm-up instantiation outside variant_selectable()");
         return UAVENV_OK;
     }
     constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
-    const bool fast = call_is_fast(p) && (p.B == h->bt);   // FAST kernels are compiled for B == BT exactly
+    // FAST kernels are compiled for B == BT exactly (PKO: there are no optional outputs to test, the three record arrays are mandatory)
+    const bool fast = (PKO ? true : call_is_fast(p)) && (p.B == h->bt);
     // PIN variant (constants pinned in VGPRs, occupancy 2) only when the launch puts between one and two wavefronts on a SIMD.
     // Sweep on one box, pinned vs unpinned (profiles/r01_v19_pin_sweep.txt): 0.67 waves/SIMD 7.50 vs 7.23 us, 1.0 tie, 1.33
     // 8.67 vs 9.20, 2.0 9.29 vs 9.77, 2.67 12.87 vs 12.08, 4.0 15.87 vs 14.98: two co-resident waves profit from constants that
@@ -333,9 +398,10 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
-        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY>), dim3(grid), blk, 0, s, PK_ARGS);     \
-        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY>), dim3(grid), blk, 0, s, PK_ARGS); \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY>), dim3(grid), blk, 0, s, PK_ARGS);       \
+        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);     \
+        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS); \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);       \
+        counted = census_count(FAM_PACKED, BT_, M, PLC_, pin ? VAR_PIN : (fast ? VAR_FAST : VAR_CHECKED), MANY_); \
     } while (0)
 #define UAVENV_LAUNCH(BT_)                                                                                       \
     do {                                                                                                         \
@@ -349,8 +415,10 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
                 if (fast) hipLaunchKernelGGL((env_kernel_multipass<BT_, M, false, true>), dim3(grid), blk, 0, s, p);  \
                 else hipLaunchKernelGGL((env_kernel_multipass<4, M, false, false>), dim3(grid), blk, 0, s, p);        \
             }                                                                                                    \
+            counted = census_count(FAM_MULTIPASS, fast ? BT_ : 4, M, h->plc, fast ? VAR_FAST : VAR_CHECKED, 0); \
         }                                                                                                        \
     } while (0)
+    bool counted = false;
     switch (h->bt) {
         case 4: UAVENV_LAUNCH(4); break;
         case 8: UAVENV_LAUNCH(8); break;
@@ -361,6 +429,7 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
 #undef UAVENV_LAUNCH_PK
 #undef PK_ARGS
     HIP_TRY(hipGetLastError());
+    if (!counted) return fail(UAVENV_E_INVALID, "launch census: no kernel launched, or an instantiation outside variant_selectable()");
     return UAVENV_OK;
 }
 
@@ -436,7 +505,7 @@ extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_s
         KParams p = h->kp;
         fill_call(p, nullptr, out);
         p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
-        return launch_env<MODE_STEP, true>(h, p, (hipStream_t)stream);
+        return launch_env<MODE_STEP, 1>(h, p, (hipStream_t)stream);
     }
     // multi-pass handles (n_ue > 64): one single-step launch per step on the same stream, each writing its own output block
     for (int t = 0; t < n_steps; ++t) {
@@ -460,6 +529,79 @@ extern "C" int uavenv_step_seq(uavenv_t *h, const int64_t *actions_dev, int n_st
         p.actions = (const long long *)actions_dev + (long long)t * h->N;   // ~8 us a Python -> ctypes -> launch round trip costs
         if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
     }
+    return UAVENV_OK;
+}
+
+// One step's nine output arrays inside the handle's scratch block (multi-pass handles only), each 256-byte aligned.
+static int scratch_outputs(uavenv_t *h, UavEnvOut *o) {
+    const size_t N = (size_t)h->N, U = (size_t)h->cfg.n_ue, B = (size_t)h->cfg.n_bs;
+    const size_t sizes[9] = {4 * N, N, 4 * N, 4 * N, 4 * N * U, 8 * N * B, N * U, 4 * N * U, 4 * N};
+    size_t off[9], total = 0;
+    for (int i = 0; i < 9; ++i) { off[i] = total; total = align_up(total + sizes[i], 256); }
+    if (!h->scratch_out && hipMalloc((void **)&h->scratch_out, total) != hipSuccess)
+        return fail(UAVENV_E_NOMEM, "step_many_packed: hipMalloc scratch outputs");
+    char *b = h->scratch_out;
+    std::memset(o, 0, sizeof(*o));
+    o->reward_dev = (float *)(b + off[0]); o->done_dev = (uint8_t *)(b + off[1]); o->mean_sinr_dev = (float *)(b + off[2]);
+    o->n_out_dev = (int32_t *)(b + off[3]); o->ue_xy_dev = (int16_t *)(b + off[4]); o->bs_xy_dev = (int32_t *)(b + off[5]);
+    o->serving_dev = (int8_t *)(b + off[6]); o->cur_sinr_dev = (float *)(b + off[7]); o->step_n_dev = (int32_t *)(b + off[8]);
+    return UAVENV_OK;
+}
+
+static OutPacked packed_block(const UavEnvOutPacked &o, long long t, long long N, long long U, long long B) {
+    OutPacked k;
+    k.walker = (WalkerOut *)o.walker_dev + t * N * U;
+    k.bs_xy = (int2 *)o.bs_xy_dev + t * N * B;
+    k.env = (StepOut *)o.env_dev + t * N;
+    return k;
+}
+
+static_assert(sizeof(UavEnvWalkerOut) == sizeof(WalkerOut) && sizeof(UavEnvStepOut) == sizeof(StepOut), "header / kernel records differ");
+
+extern "C" int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOutPacked *out, void *stream) {
+    if (!h || !actions_dev || n_steps < 0 || !out || !out->walker_dev || !out->bs_xy_dev || !out->env_dev)
+        return fail(UAVENV_E_INVALID, "step_many_packed: null handle / actions / output record array, or negative n_steps");
+    if (n_steps == 0) return UAVENV_OK;
+    DeviceGuard guard(h->device);
+    const long long N = h->N, U = h->cfg.n_ue, B = h->cfg.n_bs;
+    if (h->packed) {
+        KParams p = h->kp;
+        fill_call(p, nullptr, nullptr);
+        p.pk = packed_block(*out, 0, N, U, B);
+        p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
+        return launch_env<MODE_STEP, 2>(h, p, (hipStream_t)stream);
+    }
+    // multi-pass handles (n_ue > 64): per step one single-step launch into the scratch block, then the packing kernel
+    UavEnvOut so;
+    if (int rc = scratch_outputs(h, &so)) return rc;
+    for (int t = 0; t < n_steps; ++t) {
+        KParams p = h->kp;
+        fill_call(p, nullptr, &so);
+        p.actions = (const long long *)actions_dev + (long long)t * N; p.n_ticks = 1;
+        if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
+        const long long total = N * (U + B + 1);
+        hipLaunchKernelGGL((repack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, (int)U, (int)B,
+                           packed_block(*out, t, N, U, B), p.out);
+        HIP_TRY(hipGetLastError());
+    }
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_unpack_outputs(uavenv_t *h, const UavEnvOutPacked *in, int n_steps, const UavEnvOut *out, void *stream) {
+    if (!h || !in || !out || n_steps < 0 || !in->walker_dev || !in->bs_xy_dev || !in->env_dev)
+        return fail(UAVENV_E_INVALID, "unpack_outputs: null handle / record array / output set, or negative n_steps");
+    if (out->cur_sinr_f64_dev || out->mean_sinr_f64_dev || out->reward_f64_dev)
+        return fail(UAVENV_E_INVALID, "unpack_outputs: the packed records hold float32 values; float64 copies are not available");
+    if (n_steps == 0) return UAVENV_OK;
+    DeviceGuard guard(h->device);
+    const long long N = h->N, U = h->cfg.n_ue, B = h->cfg.n_bs;
+    KParams p = h->kp;
+    fill_call(p, nullptr, out);
+    const long long total = N * n_steps * (U + B + 1);
+    if (total > 0x7FFFFFFFll * 256) return fail(UAVENV_E_INVALID, "unpack_outputs: too many records for one launch");
+    hipLaunchKernelGGL((repack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N * n_steps, (int)U,
+                       (int)B, packed_block(*in, 0, N, U, B), p.out);
+    HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }
 
@@ -519,11 +661,12 @@ extern "C" int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream
     return UAVENV_OK;
 }
 
-extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float *out_f32_dev, double *out_f64_dev,
-                                void *stream) {
+extern "C" int uavenv_sinr_area_at(uavenv_t *h, const int32_t *bs_xy_dev, const double *fading_inj_dev, float *out_f32_dev,
+                                   double *out_f64_dev, void *stream) {
     if (!h || (!out_f32_dev && !out_f64_dev)) return fail(UAVENV_E_INVALID, "sinr_area: null handle or no output buffer");
     DeviceGuard guard(h->device);
     const KParams &k = h->kp;
+    const int32_t *cells = bs_xy_dev ? bs_xy_dev : k.bs_xy;   // GetSinrInArea(bsLoc) takes ANY bsLoc (channel.py:411); NULL = the state's
     const size_t n = (size_t)k.N * k.G * k.G;
     if (out_f32_dev) HIP_TRY(hipMemsetAsync(out_f32_dev, 0, n * sizeof(float), (hipStream_t)stream));
     if (out_f64_dev) HIP_TRY(hipMemsetAsync(out_f64_dev, 0, n * sizeof(double), (hipStream_t)stream));
@@ -532,8 +675,8 @@ extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float
     hipStream_t s = (hipStream_t)stream;
 #define UAVENV_AREA(BT_)                                                                                              \
     do {                                                                                                              \
-        if (h->plc) hipLaunchKernelGGL((sinr_area_kernel<BT_, true>), grid, blk, 0, s, k, fading_inj_dev, out_f32_dev, out_f64_dev);   \
-        else hipLaunchKernelGGL((sinr_area_kernel<BT_, false>), grid, blk, 0, s, k, fading_inj_dev, out_f32_dev, out_f64_dev);         \
+        if (h->plc) hipLaunchKernelGGL((sinr_area_kernel<BT_, true>), grid, blk, 0, s, k, cells, fading_inj_dev, out_f32_dev, out_f64_dev);   \
+        else hipLaunchKernelGGL((sinr_area_kernel<BT_, false>), grid, blk, 0, s, k, cells, fading_inj_dev, out_f32_dev, out_f64_dev);         \
     } while (0)
     switch (h->bt) {
         case 4: UAVENV_AREA(4); break;
@@ -544,6 +687,11 @@ extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float
 #undef UAVENV_AREA
     HIP_TRY(hipGetLastError());
     return UAVENV_OK;
+}
+
+extern "C" int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float *out_f32_dev, double *out_f64_dev,
+                                void *stream) {
+    return uavenv_sinr_area_at(h, nullptr, fading_inj_dev, out_f32_dev, out_f64_dev, stream);
 }
 
 // The device code paths of csrc/lean_math.h, callable on arrays: lets tests measure the accuracy of what the kernels execute

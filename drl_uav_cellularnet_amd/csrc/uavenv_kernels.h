@@ -76,6 +76,16 @@ struct OutPtrs {
     double *cur_sinr_f64, *mean_sinr_f64, *reward_f64;
 };
 
+// Packed per-step output records (include/uavenv.h: UavEnvWalkerOut / UavEnvStepOut / UavEnvOutPacked): what the nine arrays of
+// OutPtrs hold, as one 12-byte record per walker, one int2 per UAV and one 16-byte record per env.  A multi-step launch then
+// advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.
+struct alignas(4) WalkerOut { int16_t ix, iy; float cur_sinr; int8_t serving; int8_t pad0, pad1, pad2; };
+struct alignas(16) StepOut { float reward, mean_sinr; int32_t step_n; uint32_t nout_done; };   // last dword = {i16 n_out; u8 done; u8 pad}, formed
+                                                                                              // in a register so the record is ONE dwordx4 store
+__host__ __device__ constexpr uint32_t step_out_tail(int n_out, int done) { return ((uint32_t)n_out & 0xFFFFu) | ((uint32_t)(done != 0) << 16); }
+static_assert(sizeof(WalkerOut) == 12 && sizeof(StepOut) == 16, "packed output records are part of the ABI");
+struct OutPacked { WalkerOut *walker; int2 *bs_xy; StepOut *env; };   // [T][N][U], [T][N][B], [T][N]
+
 struct KParams {
     // shape / constants
     int U, B, Gr, G, W64, epw, act32;
@@ -98,6 +108,7 @@ struct KParams {
     const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
     OutPtrs out;
     unsigned long long *dbg;   // diagnostic builds only (UAVENV_STAMPS): [waves][8] s_memtime stamps
+    OutPacked pk;              // uavenv_step_many_packed (PKO kernels): packed output records instead of `out`
 };
 
 struct InitParams {
@@ -539,7 +550,7 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 // the trace modes, depth and step count during warm-up), and the whole record goes back with one 32-byte store.
 // `o`: where this step's outputs go (p.out, or the current step's block of a multi-step launch).  REC = false: outputs only
 // (steps 0 .. T-2 of a multi-step launch; the record is stored once, after the last step).
-template <int MODE, bool FAST, bool REC = true>
+template <int MODE, bool FAST, bool REC = true, bool OUTS = true>
 __device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, const StatePtrs &st, uint32_t e, EnvRec rec, uint32_t tick,
                                            int agg, int deagg, int depth, int step_n, double sum_cur, int n_outage) {
     rec.tick = tick;
@@ -548,13 +559,13 @@ __device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, c
         rec.fifo_depth = 1;                                    // bestBS_buf = [current_BS] (channel.py:115)
         rec.step_n = 0;                                        // mobile_env.py:146
         const double mean = sum_cur * p.inv_U;
-        if (UAV_OUT(o.step_n)) stx(o.step_n, e, 0);
-        if (UAV_OUT(o.reward)) stx(o.reward, e, 0.f);
-        if (UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, 0.0);
-        if (UAV_OUT(o.done)) stx(o.done, e, 0);
-        if (UAV_OUT(o.n_out)) stx(o.n_out, e, 0);
-        if (UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
-        if (UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
+        if (OUTS && UAV_OUT(o.step_n)) stx(o.step_n, e, 0);
+        if (OUTS && UAV_OUT(o.reward)) stx(o.reward, e, 0.f);
+        if (OUTS && UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, 0.0);
+        if (OUTS && UAV_OUT(o.done)) stx(o.done, e, 0);
+        if (OUTS && UAV_OUT(o.n_out)) stx(o.n_out, e, 0);
+        if (OUTS && UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
+        if (OUTS && UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
     }
     if (is_step(MODE)) {
         rec.fifo_depth = depth < 3 ? depth + 1 : depth;
@@ -565,13 +576,13 @@ __device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, c
         if (-1.0 > reward) reward = -1.0;                     // max(.., -1)  mobile_env.py:189
         step_n += 1;                                          // mobile_env.py:181
         rec.step_n = step_n;
-        if (UAV_OUT(o.step_n)) stx(o.step_n, e, step_n);
-        if (UAV_OUT(o.done)) stx(o.done, e, (uint8_t)(step_n >= p.max_step));
-        if (UAV_OUT(o.reward)) stx(o.reward, e, (float)reward);
-        if (UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, reward);
-        if (UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
-        if (UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
-        if (UAV_OUT(o.n_out)) stx(o.n_out, e, n_outage);
+        if (OUTS && UAV_OUT(o.step_n)) stx(o.step_n, e, step_n);
+        if (OUTS && UAV_OUT(o.done)) stx(o.done, e, (uint8_t)(step_n >= p.max_step));
+        if (OUTS && UAV_OUT(o.reward)) stx(o.reward, e, (float)reward);
+        if (OUTS && UAV_OUT64(o.reward_f64)) stx(o.reward_f64, e, reward);
+        if (OUTS && UAV_OUT(o.mean_sinr)) stx(o.mean_sinr, e, (float)mean);
+        if (OUTS && UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
+        if (OUTS && UAV_OUT(o.n_out)) stx(o.n_out, e, n_outage);
     }
     if (REC) stx(st.env, e, rec);
 }
@@ -593,6 +604,18 @@ __device__ __forceinline__ void out_next_step(OutPtrs &o, long long N, int U, in
     if (UAV_OUT64(o.cur_sinr_f64)) o.cur_sinr_f64 += nu;
     if (UAV_OUT64(o.mean_sinr_f64)) o.mean_sinr_f64 += N;
     if (UAV_OUT64(o.reward_f64)) o.reward_f64 += N;
+}
+
+// One step's per-env outputs as ONE 16-byte record (PKO kernels): the arithmetic of env_finish's step branch
+// (mobile_env.py:163-189; channel.py:216), `step_n` = the count BEFORE this step.
+__device__ __forceinline__ void env_finish_packed(const KParams &p, StepOut *dst, uint32_t e, int step_n, double sum_cur, int n_outage) {
+    const double mean = sum_cur * p.inv_U;
+    const double r0 = sum_cur * p.inv_U20;
+    const double r1 = -((double)n_outage * p.inv_U);
+    double reward = (0.0 + r0) + r1;
+    if (-1.0 > reward) reward = -1.0;
+    step_n += 1;
+    stx(dst, e, StepOut{(float)reward, (float)mean, step_n, step_out_tail(n_outage, step_n >= p.max_step)});
 }
 
 // ================================================================================================
@@ -653,11 +676,13 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // computes) and writes block t of every output array.  Exactly the arithmetic of p.n_ticks single-step launches, so results
 // are bit-identical (tests/test_step_many_gpu.py); what disappears is the per-step launch, kernarg fetch, state load round
 // trip and state store, i.e. the fixed ~5.8 us a 4096-env launch spends outside its arithmetic.
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false>
+// PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
                                                                               int Gr, int B_rt, int lane_magic, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
+    static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
     // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
     // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
@@ -766,6 +791,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     int n_outage = 0;
     unsigned long long ob = 0ull;
     OutPtrs om = p.out;                                // MANY: the current step's output blocks (dead code otherwise)
+    OutPacked ok = p.pk;                               // PKO: the current step's record blocks
     for (int it = 0; it < n_ticks; ++it) {
         long long act_next = 0;
         if (MANY) {                                    // prefetch the next step's action: its round trip hides behind this step
@@ -870,7 +896,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
             sum_cur = slot_sum(live ? cur : 0.0, ul, U);
         }
-        if (MANY) {
+        if (PKO) {
+            // ---- this step's outputs as packed records: three stores, three advancing pointers ---------------------------
+            if (live) stx(ok.walker, iu32, WalkerOut{(int16_t)ix, (int16_t)iy, (float)cur, (int8_t)serving, 0, 0, 0});
+            if (bown) stx(ok.bs_xy, ib32, int2{bx, by});
+            if (head) env_finish_packed(p, ok.env, e32, step_n, sum_cur, n_outage);
+            if (it + 1 < n_ticks) {
+                ok.walker += N * U; ok.bs_xy += N * B; ok.env += N;
+                prev_out = ob;
+                depth = depth < 3 ? depth + 1 : depth;
+                step_n += 1;
+                act = act_next;
+            }
+        } else if (MANY) {
             // ---- this step's outputs (block `it` of every output array), then the hand-over to the next step ------------
             if (live) {
                 if (UAV_OUT(om.ue_xy)) { stx(om.ue_xy, 2u * iu32, (int16_t)ix); stx(om.ue_xy, 2u * iu32 + 1u, (int16_t)iy); }
@@ -919,7 +957,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         const uint32_t ew = block_local<!PIN>(e32);
         if (MODE != MODE_WARMUP) stx(st.out_bits, ew, ob);                                // :116 / :173
         // (MANY: outputs of the LAST step + the record; depth / step_n are the values that step started from)
-        env_finish<MODE, FAST>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        if (PKO) env_finish<MODE, FAST, true, false>(p, p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);   // record only
+        else env_finish<MODE, FAST>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -1326,8 +1365,8 @@ __global__ __launch_bounds__(256) void obs_cells_kernel(long long N, int U, int 
 // fading_inj: [N, (G-1)^2, B] in the reference's call order per cell (interferers ascending, then the nearest UAV).
 // ================================================================================================
 template <int BT, bool PLC>
-__global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const double *fading_inj, float *out32,
-                                                        double *out64) {
+__global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const int32_t *bs_xy, const double *fading_inj, float *out32,
+                                                        double *out64) {   // bs_xy [N,B,2]: the state's cells or the caller's bsLoc
     const int B = p.B, G = p.G, W = G - 1;
     const long long cells = (long long)W * W;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1343,7 +1382,7 @@ __global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const d
     for (int b = 0; b < BT; ++b) {
         int v = 0x7FFFFFFF;
         if (b < B) {
-            const int dx = x - p.bs_xy[(e * B + b) * 2], dy = y - p.bs_xy[(e * B + b) * 2 + 1];
+            const int dx = x - bs_xy[(e * B + b) * 2], dy = y - bs_xy[(e * B + b) * 2 + 1];
             v = dx * dx + dy * dy;                                   // distance ignores z (GetDistance, :220-226)
         }
         d2i[b] = v;
@@ -1393,6 +1432,46 @@ __global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const d
     const long long o = e * (long long)G * G + (long long)x * G + y;
     if (out32) out32[o] = (float)s;
     if (out64) out64[o] = s;
+}
+
+// ================================================================================================
+// Packed output records <-> the nine output arrays, for n_blocks steps ([T][...] on both sides).  One thread per walker / UAV /
+// env of a step; null members of `o` are skipped.  TO_PACKED = false: uavenv_unpack_outputs; true: the multi-pass handles'
+// uavenv_step_many_packed (their step kernel writes the nine arrays of a scratch block, this kernel packs it).
+// ================================================================================================
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void repack_kernel(long long n_env_steps, int U, int B, OutPacked k, OutPtrs o) {
+    const long long per = (long long)U + B + 1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_env_steps * per) return;
+    const long long e = t / per;                       // (step, env) pair
+    const int r = (int)(t - e * per);
+    if (r < U) {
+        const long long i = e * U + r;
+        if (TO_PACKED) {
+            k.walker[i] = WalkerOut{o.ue_xy[2 * i], o.ue_xy[2 * i + 1], o.cur_sinr[i], o.serving[i], 0, 0, 0};
+        } else {
+            const WalkerOut w = k.walker[i];
+            if (o.ue_xy) { o.ue_xy[2 * i] = w.ix; o.ue_xy[2 * i + 1] = w.iy; }
+            if (o.serving) o.serving[i] = w.serving;
+            if (o.cur_sinr) o.cur_sinr[i] = w.cur_sinr;
+        }
+    } else if (r < U + B) {
+        const long long i = e * B + (r - U);
+        if (TO_PACKED) k.bs_xy[i] = int2{o.bs_xy[2 * i], o.bs_xy[2 * i + 1]};
+        else if (o.bs_xy) { const int2 c = k.bs_xy[i]; o.bs_xy[2 * i] = c.x; o.bs_xy[2 * i + 1] = c.y; }
+    } else {
+        if (TO_PACKED) {
+            k.env[e] = StepOut{o.reward[e], o.mean_sinr[e], o.step_n[e], step_out_tail(o.n_out[e], o.done[e])};
+        } else {
+            const StepOut v = k.env[e];
+            if (o.reward) o.reward[e] = v.reward;
+            if (o.mean_sinr) o.mean_sinr[e] = v.mean_sinr;
+            if (o.step_n) o.step_n[e] = v.step_n;
+            if (o.n_out) o.n_out[e] = (int16_t)(v.nout_done & 0xFFFFu);
+            if (o.done) o.done[e] = (uint8_t)((v.nout_done >> 16) & 1u);
+        }
+    }
 }
 
 }  // namespace uavk

@@ -47,13 +47,16 @@ class _ChannelView:
         return np.array(self._o._dense()[1:])
 
     def GetSinrInArea(self, bsLoc=None):
-        """(G, G) float64 dB map of the nearest-UAV DL SINR with fresh shadowing (channel.py:411-433), for the env's
-        current UAV cells -- which is what every caller passes (main_test.py:89: info.bs_loc)."""
+        """(G, G) float64 dB map of the nearest-UAV DL SINR with fresh shadowing (channel.py:411-433) for the UAV cells
+        ``bsLoc`` (default: the env's current cells, which is what every caller passes -- main_test.py:89: info.bs_loc)."""
         import torch
 
-        if bsLoc is not None and not np.array_equal(np.asarray(bsLoc)[:, :2], self._o.bsLoc[:, :2]):
-            raise NotImplementedError("GetSinrInArea is evaluated for the env's current UAV cells only")
-        return self._o._env.sinr_area(dtype=torch.float64)[0].cpu().numpy()
+        cells = None
+        if bsLoc is not None:                                   # any (nBS, >= 2) array, as channel.py:411 accepts (z is ignored, Q1)
+            cells = np.asarray(bsLoc)[:, :2].astype(np.int32).reshape(1, -1, 2)
+            if cells.shape[1] != self._o.nBS:
+                raise ValueError("bsLoc must have nBS rows")     # the reference indexes interfDL[bs_id] of ITS nBS (channel.py:425)
+        return self._o._env.sinr_area(dtype=torch.float64, bs_xy=cells)[0].cpu().numpy()
 
 
 class MobiEnvironment:

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 3   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq */
+#define UAVENV_ABI_VERSION 4   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
+                                * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census) */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -132,6 +133,23 @@ int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj
  * keep stepping with done = 1.  n_ue <= 64: walker / group / UAV state stays in registers across the steps (no per-step launch,
  * state load or state store); n_ue > 64: n_steps single-step launches on `stream`. */
 int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream);
+/* uavenv_step_many with the outputs of a step as RECORDS instead of nine arrays: one 12-byte record per walker (what
+ * ue_xy / cur_sinr / serving hold), the UAV cells as they are, one 16-byte record per env (reward, mean_sinr, step_n, n_out,
+ * done).  Same steps, same values (tests/test_step_many_gpu.py: bit-identical after uavenv_unpack_outputs); the multi-step kernel
+ * then advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.  All three arrays are mandatory:
+ * walker_dev [n_steps, N, U], bs_xy_dev [n_steps, N, B, 2], env_dev [n_steps, N].  n_ue > 64: single-step launches + a packing
+ * kernel per step (a scratch output block is allocated on the first such call: not inside a captured region). */
+typedef struct UavEnvWalkerOut { int16_t ix, iy; float cur_sinr; int8_t serving; int8_t _pad[3]; } UavEnvWalkerOut;            /* 12 B */
+typedef struct UavEnvStepOut { float reward, mean_sinr; int32_t step_n; int16_t n_out; uint8_t done, _pad; } UavEnvStepOut;   /* 16 B */
+typedef struct UavEnvOutPacked {
+    UavEnvWalkerOut *walker_dev;
+    int32_t *bs_xy_dev;
+    UavEnvStepOut *env_dev;
+} UavEnvOutPacked;
+int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOutPacked *out, void *stream);
+/* Records of n_steps steps -> the nine arrays of `out`, [n_steps, ...] each (NULL members are skipped; float64 copies are refused:
+ * the records hold float32). */
+int uavenv_unpack_outputs(uavenv_t *h, const UavEnvOutPacked *in, int n_steps, const UavEnvOut *out, void *stream);
 /* The same n_steps steps as n_steps ordinary launches of the single-step kernel issued by ONE host call: step t reads row t of
  * actions_dev [n_steps, N]; `out` is the single-step output set, overwritten by every step (it holds the last step's results
  * afterwards), exactly as n_steps calls of uavenv_step would leave it.  For callers that pay a high price per host call
@@ -158,6 +176,10 @@ int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream);
  * fading_inj_dev: [N,(G-1)^2,B] draws in the reference's call order per cell (interferers ascending, then the nearest
  * UAV), or NULL for the on-device Philox stream. */
 int uavenv_sinr_area(uavenv_t *h, const double *fading_inj_dev, float *out_f32_dev, double *out_f64_dev, void *stream);
+/* The same for ANY UAV cells, as the reference's signature GetSinrInArea(bsLoc) allows (channel.py:411): bs_xy_dev int32 [N,B,2]
+ * (B = the handle's n_bs; NULL = the cells in the state, i.e. uavenv_sinr_area).  The state is not modified. */
+int uavenv_sinr_area_at(uavenv_t *h, const int32_t *bs_xy_dev, const double *fading_inj_dev, float *out_f32_dev,
+                        double *out_f64_dev, void *stream);
 
 /* copy.deepcopy(env) (gradient.py:15) / checkpointing: the whole persistent state as one blob. */
 int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout);
@@ -168,6 +190,15 @@ int uavenv_set_state(uavenv_t *h, const void *src, int src_is_device, void *stre
  * device: op 0 a/b (lm_div: b positive normal), 1 1/sqrt(a), 2 ln(a), 3 2^a, 4 sin(pi a) -> out0, cos(pi a) -> out1.  Test hook:
  * tests/test_lean_math_gpu.py measures their error against long double. */
 int uavenv_lean_math_eval(int op, const double *a_dev, const double *b_dev, double *out0_dev, double *out1_dev, int64_t n, void *stream);
+
+/* Launch census (test hook): the env kernels are templates, and every call picks ONE instantiation from (kernel family, bound on
+ * n_bs, mode, path-loss form, checked / fast / pinned variant, multi-step).  Entry i of uavenv_debug_variant_count() entries:
+ * its name, whether the dispatch logic can select it at all, and how often this process has launched it since start /
+ * uavenv_debug_variant_reset().  tests/test_launch_variants_gpu.py launches every selectable instantiation against the oracle
+ * and asserts that none is left at zero. */
+int uavenv_debug_variant_count(void);
+int uavenv_debug_variant_info(int i, char *name, size_t name_len, int *selectable, long long *launches);
+void uavenv_debug_variant_reset(void);
 
 /* Philox4x32-10 of one counter/key on the HOST (known-answer tests of the generator the kernels use). */
 void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

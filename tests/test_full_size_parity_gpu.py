@@ -66,11 +66,14 @@ def test_bench_sized_batches_match_the_oracle_on_windows(n_envs):
             _compare(env.out, o.step(a_np[k:k + WIN]), k, "step %d" % t)
 
 
-def test_step_many_and_graph_at_4096_envs_match_the_oracle_on_windows():
+@pytest.mark.parametrize("n", [4096, 8192, 65536])
+def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n):
+    """4096 envs: the pinned multi-step kernel; 8192 / 65536: the UNPINNED one (more than two wavefronts per SIMD), the
+    instantiation behind DESIGN section 5's 65 536-env `step_many` figure."""
     torch = _torch()
-    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, _capi
 
-    n = 4096
+    census0 = {name: cnt for name, _, cnt in _capi.launch_census()}
     env_m = BatchedMobiEnv(n, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], seed=0x5EED)
     env_g = env_m.clone()
     orcs = _oracles(n)
@@ -89,6 +92,52 @@ def test_step_many_and_graph_at_4096_envs_match_the_oracle_on_windows():
             if t == STEPS - 1:
                 _compare(env_g.out, want, k, "graph replay, last step")
     assert np.array_equal(env_m.get_state(), env_g.get_state())
+    ran = [name for name, _, cnt in _capi.launch_census() if cnt > census0[name] and "MANY=1" in name]
+    assert ran == ["env_kernel_packed<BT=4, STEP, PLC=1, FAST=1, PIN=%d, MANY=1>" % (1 if n == 4096 else 0)], ran
+
+
+@pytest.mark.parametrize("n_envs", [8192])
+def test_config5_at_full_size_matches_the_oracle_on_windows(n_envs):
+    """BASELINE configs[4]: 16 UAV x 200 UE, 8192 envs -- env_kernel_multipass<16, STEP, cube, FAST> at the 8192 wavefronts
+    profiles/r02e_config5_kernel_stats.csv times -- 8 steps against 8-env oracle windows at the start, in the middle and at the
+    end of the batch.  Integers (cells, serving UAV, outage count, step counter) EXACT over every window and step: the multi-pass
+    kernel sums the interference of the best UAV in a different order than the reference, which could only
+    show as a flipped handover / outage decision."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, _capi
+    from oracle import oracle as O
+
+    B, U, Gd, W, T = 16, 200, 100, 8, 8
+    bs_init = [(Gd // 8 + (b // 4) * (Gd // 4), Gd // 8 + (b % 4) * (Gd // 4)) for b in range(B)]      # 4 x 4 lattice (SURVEY 8d C5)
+    census0 = {name: cnt for name, _, cnt in _capi.launch_census()}
+    env = BatchedMobiEnv(n_envs, nBS=B, nUE=U, grid_n=Gd, groups=[50] * 4, bs_init=bs_init, seed=0x5EED)
+    cfg = O.make_config(B, U, Gd, groups=[50] * 4, bs_init=bs_init)
+    orcs = []
+    for k in sorted({0, n_envs // 2 + 3, n_envs - W}):
+        o = O.OracleEnv(cfg, W, seed=0x5EED, env_id_base=k)
+        orcs.append((k, o, {kk: v.copy() for kk, v in o.construct().items()}))
+
+    def cmp(want, k, what):
+        for key in INT_KEYS:
+            assert np.array_equal(env.out[key][k:k + W].cpu().numpy(), want[key]), "%s: %s differs, window %d" % (what, key, k)
+        for key in F32_KEYS:
+            np.testing.assert_allclose(env.out[key][k:k + W].cpu().numpy(), want[key], rtol=1e-5, atol=0,
+                                       err_msg="%s: %s, window %d" % (what, key, k))
+
+    for k, _, first in orcs:
+        cmp(first, k, "constructor")
+    gen = torch.Generator().manual_seed(4321)
+    for t in range(T):
+        digits = torch.randint(0, 5, (n_envs, B), generator=gen, dtype=torch.int64)
+        a = torch.zeros(n_envs, dtype=torch.int64)
+        for b in range(B):
+            a = a * 5 + digits[:, b]                                  # joint action in [0, 5^16): needs the int64 decode
+        env.step(a.to(env.device))
+        a_np = a.numpy()
+        for k, o, _ in orcs:
+            cmp(o.step(a_np[k:k + W]), k, "step %d" % t)
+    ran = [name for name, _, cnt in _capi.launch_census() if cnt > census0[name] and "STEP" in name]
+    assert ran == ["env_kernel_multipass<BT=16, STEP, PLC=1, FAST=1>"], ran
 
 
 def test_a2c_config3_at_full_size():

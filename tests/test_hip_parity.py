@@ -345,6 +345,36 @@ def test_hip_sinr_area_matches_reference(name):
         np.testing.assert_allclose(got32[n], want.astype(np.float32), rtol=F32_RTOL, atol=0)
 
 
+def test_hip_sinr_area_for_any_bs_loc_matches_reference():
+    """GetSinrInArea(bsLoc) takes ANY bsLoc (channel.py:411): uavenv_sinr_area_at with the fixture's five UAV cells passed as an
+    override on a handle whose own UAVs sit elsewhere reproduces the map the real reference produced for those cells, and leaves
+    the handle's state alone."""
+    import os
+
+    torch = _torch()
+    from conftest import GOLDEN_DIR
+
+    with np.load(os.path.join(GOLDEN_DIR, "ref_area_5bs_g40_seed8.npz"), allow_pickle=False) as z:
+        seed, G, B, bs, want = int(z["seed"]), int(z["grid"]), int(z["n_bs"]), z["bs_xy"], z["sinr_area"]
+    N = 2
+    elsewhere = [(3 + 7 * b, 36 - 7 * b) for b in range(B)]
+    assert not any(tuple(r) in elsewhere for r in bs)
+    env = _make(N, nBS=B, nUE=8, grid_n=G, groups=[2, 2, 2, 2], bs_init=elsewhere, construct=False)
+    env.init()
+    before = env.get_state()
+    fading = np.random.RandomState(seed).normal(0.0, 2.0, size=((G - 1) * (G - 1), B))
+    f = np.broadcast_to(fading, (N,) + fading.shape)
+    cells = np.broadcast_to(np.asarray(bs, np.int32)[:, :2], (N, B, 2))
+    got = env.sinr_area(fading=f, dtype=torch.float64, bs_xy=cells).cpu().numpy()
+    own = env.sinr_area(fading=f, dtype=torch.float64).cpu().numpy()
+    for n in range(N):
+        np.testing.assert_allclose(got[n], want, rtol=1e-9, atol=1e-9)
+    assert np.abs(own[0] - want).max() > 1.0                                 # the handle's own cells give another map
+    assert np.array_equal(env.get_state(), before)
+    with pytest.raises(ValueError):
+        env.sinr_area(bs_xy=cells[:, :4])
+
+
 def test_hip_sinr_area_matches_oracle_on_philox_streams():
     torch = _torch()
     from oracle import oracle as O
@@ -400,7 +430,7 @@ def test_production_fast_variant_matches_oracle(shape, pin, monkeypatch):
     torch = _torch()
     from oracle import oracle as O
 
-    monkeypatch.setenv("UAVENV_FORCE_PIN", pin)          # read by the launcher at every launch
+    monkeypatch.setenv("UAVENV_FORCE_PIN", pin)          # read ONCE, in uavenv_create: set before the env below is built
     B, U, G, N = shape[:4]
     n_act = shape[4] if len(shape) > 4 else 5                     # (5^B must fit int64: B = 32 runs with two actions per UAV)
     over = {} if n_act == 5 else {"n_act": n_act}

@@ -200,8 +200,13 @@ def test_shim_get_sinr_in_area_shape_and_determinism():
     assert (m[0] == 0).all() and (m[:, 0] == 0).all() and np.isfinite(m).all()
     bx, by = info.bs_loc[0][:2]
     assert m[bx, by] > 60.0                                           # a cell under a UAV: d = 0 -> loss 0
-    with pytest.raises(NotImplementedError):
-        env.channel.GetSinrInArea(info.bs_loc + 1)
+    moved = info.bs_loc + np.array([3, -2, 0])                        # ANY bsLoc, as channel.py:411 accepts
+    m2 = env.channel.GetSinrInArea(moved)
+    assert m2.shape == (100, 100) and m2[moved[0][0], moved[0][1]] > 60.0 and not np.array_equal(m2, m)
+    assert np.array_equal(env.channel.GetSinrInArea(info.bs_loc), m)  # same tick, same cells: the same Philox draws
+    assert np.array_equal(env.bsLoc, info.bs_loc)                     # the env's own UAVs did not move
+    with pytest.raises(ValueError):
+        env.channel.GetSinrInArea(info.bs_loc[:3])
 
 
 def test_eval_harness_like_main_test_py(tmp_path):

@@ -35,9 +35,15 @@ SHAPES = [(100, 4, 20, 1), (100, 4, 20, 2), (100, 4, 20, 7), (1366 * 3 - 1, 4, 2
           (10, 16, 60, 6), (4, 16, 200, 3)]
 
 
+@pytest.mark.parametrize("pin", [None, "0", "1"], ids=["auto", "unpinned", "pinned"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%denv_%dx%d_T%d" % s)
-def test_step_many_is_bit_identical_to_single_steps(shape):
+def test_step_many_is_bit_identical_to_single_steps(shape, pin, monkeypatch):
+    """`pin`: the launcher's own choice, or UAVENV_FORCE_PIN (read once in uavenv_create, so set BEFORE the env exists): "0" runs
+    env_kernel_packed<..., FAST, PIN = false, MANY = true>, the instantiation uavenv_step_many selects above two wavefronts per
+    SIMD (> 6144 envs at 20 UEs) -- here on small batches; tests/test_full_size_parity_gpu.py runs it at 8192 / 65536 envs."""
     torch = _torch()
+    if pin is not None:
+        monkeypatch.setenv("UAVENV_FORCE_PIN", pin)
     n, n_bs, n_ue, T = shape
     env = _env(n, n_bs, n_ue, f64_outputs=(n_bs == 3))
     ref = env.clone()
@@ -55,6 +61,64 @@ def test_step_many_is_bit_identical_to_single_steps(shape):
     env.step(a); ref.step(a)
     for k, v in ref.out.items():
         assert torch.equal(env.out[k], v), k
+
+
+@pytest.mark.parametrize("pin", [None, "0", "1"], ids=["auto", "unpinned", "pinned"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%denv_%dx%d_T%d" % s)
+def test_step_many_packed_unpacks_to_exactly_what_step_many_returns(shape, pin, monkeypatch):
+    """uavenv_step_many_packed (one record per walker / env and step) + uavenv_unpack_outputs == uavenv_step_many on all nine
+    arrays of every step, and the same final state: the packed-output kernels compute the same steps."""
+    torch = _torch()
+    if pin is not None:
+        monkeypatch.setenv("UAVENV_FORCE_PIN", pin)
+    n, n_bs, n_ue, T = shape
+    env = _env(n, n_bs, n_ue)
+    ref = env.clone()
+    act = _actions(torch, env, T, 6)
+    pk = env.step_many_packed(act)
+    got = env.unpack_outputs(pk)
+    want = ref.step_many(act)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert np.array_equal(env.get_state(), ref.get_state())
+    # the records decode on the host with the documented layouts
+    w = pk["walker"].cpu().numpy().view(env.WALKER_OUT_DTYPE)[..., 0]
+    e = pk["env"].cpu().numpy().view(env.STEP_OUT_DTYPE)[..., 0]
+    assert np.array_equal(w["ix"], want["ue_xy"][..., 0].cpu().numpy()) and np.array_equal(w["serving"], want["serving"].cpu().numpy())
+    assert np.array_equal(e["n_out"], want["n_out"].cpu().numpy()) and np.array_equal(e["done"], want["done"].cpu().numpy())
+    assert np.array_equal(e["reward"], want["reward"].cpu().numpy())
+    # a second call reuses the record buffers and continues from the stored state
+    env.step_many_packed(act, out=pk)
+    ref.step_many(act, out=want)
+    got2 = env.unpack_outputs(pk, out=got)
+    for k in want:
+        assert torch.equal(got2[k], want[k]), k
+
+
+def test_step_many_packed_rejects_bad_arguments():
+    torch = _torch()
+    import ctypes as C
+
+    from drl_uav_cellularnet_amd import _capi
+
+    env = _env(64, 4, 20)
+    act = _actions(torch, env, 2, 3)
+    pk = env.step_many_packed(act)
+    st = env.packed_out_struct(pk)
+    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), 0, C.byref(st), env._stream()) == 0
+    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), -1, C.byref(st), env._stream()) != 0
+    assert env._lib.uavenv_step_many_packed(env._h, None, 2, C.byref(st), env._stream()) != 0
+    bad = _capi.UavEnvOutPacked()
+    bad.walker_dev, bad.bs_xy_dev = st.walker_dev, st.bs_xy_dev                # env_dev missing: all three arrays are mandatory
+    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), 2, C.byref(bad), env._stream()) != 0
+    f64env = _env(8, 4, 20, f64_outputs=True)
+    full = {k: torch.empty((2,) + tuple(v.shape), dtype=v.dtype, device=v.device) for k, v in f64env.out.items()}
+    pk8 = f64env.step_many_packed(_actions(torch, f64env, 2, 4))
+    with pytest.raises(_capi.UavEnvError):
+        f64env.unpack_outputs(pk8, out=full)                                   # float64 copies cannot come out of float32 records
+    with pytest.raises(ValueError):
+        env.step_many_packed(act[:1], out=pk)
 
 
 def test_step_many_long_run_crosses_phases_done_and_matches_oracle():
