@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/s of the HIP hot path (BASELINE.json metric), one JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--launch graph|eager|many] [--mode env|a2c]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--grid G] [--launch many|manypk|seq|graph|eager] [--mode env|a2c]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one batched MobiEnvironment.step() over all envs of a rank (mobile_env.py:150-194).
@@ -17,6 +17,8 @@ ranks (one process per GPU, spawned before anything touches the GPU) and fails l
                    between them (the benchmark's actions are resident in HBM and do not depend on observations, which is the
                    case this entry point exists for).  A 4096-env single-step kernel lasts 8 us whatever launches it, 5.8 us of it
                    outside its arithmetic (kernarg fetch, state load round trip, store drain: DESIGN.md section 4).
+            manypk uavenv_step_many_packed: the same launch with one 12-byte record per walker and one 16-byte record per env and
+                   step instead of nine arrays (3 stores per step instead of 12)
             seq    uavenv_step_seq: one kernel per step, the launches of <= 100 steps issued by ONE C call
             graph  hipGraph replay of chunks of <= 100 captured uavenv_step launches (same steady state; a replay costs 10-20 us
                    of host latency before the first kernel, which a 20-step run feels)
@@ -61,22 +63,27 @@ def transcendental_evals_per_env_step(U, B):
     return U * (4 + 3 * hb + 2 * B)
 
 
-STEP_KERNEL = "env_kernel_packed<4, 2, true, true, true, false>"   # rocprofv3 name (template part) of the single-step kernel of this workload
-
-
-def committed_counters(envs, kernel):
+def committed_counters(envs, n_bs, n_ue, kernel):
     """Per-launch PMC figures of a step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
-    cannot run the profiler on itself, so these are constants of the profiled build, labelled as such in the line.  None when
-    that file does not describe this kernel / batch size."""
+    cannot run the profiler on itself, so these are constants of the profiled build, labelled as such in the line.  `kernel` is the
+    instantiation the timed region launched, as the library's launch census names it.  None when no committed pass describes this
+    (kernel, batch size, shape)."""
     path = os.path.join(ROOT, "profiles", "traffic_current.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return None
-    if t.get("envs") != envs or t.get("n_ue") != N_UE or t.get("n_bs") != N_BS:
-        return None
-    return t.get("kernels", {}).get(kernel)
+    for e in t.get("entries", []):
+        if (e.get("envs"), e.get("n_bs"), e.get("n_ue"), e.get("kernel")) == (envs, n_bs, n_ue, kernel):
+            return e
+    return None
+
+
+def launched_kernels(before, after):
+    """Names of the env-kernel instantiations launched between two census snapshots (step kernels only), most launches first."""
+    d = [(a[2] - b[2], a[0]) for a, b in zip(after, before) if a[2] > b[2] and ("STEP" in a[0])]
+    return [name for _, name in sorted(d, reverse=True)]
 
 
 def cpu_baseline(target_seconds=12.0):
@@ -211,7 +218,9 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
     ap.add_argument("--mode", choices=("env", "a2c"), default="env")
-    ap.add_argument("--launch", choices=("many", "seq", "graph", "eager"), default="many")
+    ap.add_argument("--launch", choices=("many", "manypk", "seq", "graph", "eager"), default="many")
+    ap.add_argument("--grid", type=int, default=GRID, help="grid cells per side (100 = every reference script; 200 = the class default, "
+                    "mobile_env.py:37; the default run also reports G = 200 under other_grids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-a2c", action="store_true", help="env mode: skip the appended A2C / gradient all-reduce measurement")
     ap.add_argument("--no-alt", action="store_true", help="env mode: skip the secondary eager / step_many measurements")
@@ -276,6 +285,7 @@ class EnvRun:
         self.tape = torch.empty((CHUNK, env.n_envs), dtype=torch.int64, device=env.device)
         self.graphs = {}
         self.many_out = {}
+        self.pk_out = {}
         self.max_step = int(env.cfg.max_step)
         self.t = 0            # steps since the last reset (the constructor's reset counts as one)
         self.cursor = 0       # next pool row
@@ -290,6 +300,11 @@ class EnvRun:
             if self.launch == "many" and n not in self.many_out:
                 self.many_out[n] = {k: torch.empty((n,) + tuple(v.shape), dtype=v.dtype, device=v.device)
                                     for k, v in self.env.out.items()}
+            if self.launch == "manypk" and n not in self.pk_out:
+                e = self.env
+                self.pk_out[n] = {"walker": torch.empty((n, e.n_envs, e.nUE, 12), dtype=torch.uint8, device=e.device),
+                                  "bs_xy": torch.empty((n, e.n_envs, e.nBS, 2), dtype=torch.int32, device=e.device),
+                                  "env": torch.empty((n, e.n_envs, 16), dtype=torch.uint8, device=e.device)}
 
     def plan(self, n_steps, t0=None):
         """Segment lengths for n_steps more steps, cut at reset boundaries: [(n, reset_after)]."""
@@ -343,6 +358,10 @@ class EnvRun:
                 st = env.out_struct_for(self.many_out[n])
                 self._keep_structs = getattr(self, "_keep_structs", []) + [st]
                 prog.append(functools.partial(env._lib.uavenv_step_many, env._h, self.tape.data_ptr(), n, C.byref(st), stream))
+            elif self.launch == "manypk":
+                st = env.packed_out_struct(self.pk_out[n])
+                self._keep_structs = getattr(self, "_keep_structs", []) + [st]
+                prog.append(functools.partial(env._lib.uavenv_step_many_packed, env._h, self.tape.data_ptr(), n, C.byref(st), stream))
             else:
                 prog.extend(functools.partial(env.step, self.tape[t]) for t in range(n))
             self.t += n
@@ -364,6 +383,8 @@ class EnvRun:
                 env.step_seq(self.tape[:n])
             elif self.launch == "many":
                 env.step_many(self.tape[:n], out=self.many_out[n], refresh_out=False)
+            elif self.launch == "manypk":
+                env.step_many_packed(self.tape[:n], out=self.pk_out[n])
             else:
                 for t in range(n):
                     env.step(self.tape[t])
@@ -400,7 +421,7 @@ def timed(fn, dist, dev):
 def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=None):
     import torch
 
-    from drl_uav_cellularnet_amd.sharding import max_over_ranks
+    from drl_uav_cellularnet_amd.sharding import gather_over_ranks, max_over_ranks
 
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     n_pool = max(CHUNK, min(((K + W + CHUNK - 1) // CHUNK) * CHUNK, 5 * CHUNK))    # action pool resident in HBM, cycled
@@ -424,14 +445,18 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         for f in prog:
             results.append(f())
 
+    from drl_uav_cellularnet_amd import _capi
+
+    census0 = _capi.launch_census()
     elapsed, gpu_ms = timed(go, dist, dev)
+    kernels = launched_kernels(census0, _capi.launch_census())          # the instantiation(s) the timed region really launched
     bad = [r for r in results if isinstance(r, int) and r != 0]          # return codes of the bound C-ABI launches
     if bad:
-        from drl_uav_cellularnet_amd import _capi
-
         _capi.check(bad[0])
+    per_rank = gather_over_ranks([elapsed, gpu_ms], device=reduce_dev)   # every rank's own clock: a straggler must be visible
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
-    return elapsed, gpu_ms
+    return elapsed, gpu_ms, {"kernels": kernels, "per_rank_elapsed_s": [p[0] for p in per_rank],
+                             "per_rank_gpu_ms": [p[1] for p in per_rank]}
 
 
 def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollout_len=A2C_ROLLOUT):
@@ -441,11 +466,11 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
 
     from drl_uav_cellularnet_amd import BatchedMobiEnv
     from drl_uav_cellularnet_amd.agent import A2CRunner, grad_allreduce_bytes
-    from drl_uav_cellularnet_amd.sharding import max_over_ranks, shard_for_rank, whole_job_rate
+    from drl_uav_cellularnet_amd.sharding import gather_over_ranks, max_over_ranks, shard_for_rank, whole_job_rate
 
     base, _ = shard_for_rank(rank, world, envs)
     env = BatchedMobiEnv(envs, nBS=N_BS, nUE=N_UE, grid_n=GRID, groups=GROUPS, device=dev, seed=SEED, env_id_base=base)
-    runner = A2CRunner(env, rollout=rollout_len)
+    runner = A2CRunner(env, rollout=rollout_len, tune_gemms=True)     # opt-in: the shipped TunableOp picks for the config-3 GEMM shapes
     runner.train_rollout()                                         # untimed: allocator, rocBLAS / RCCL first use, graph capture
     prof = {"collect": 0.0, "update": 0.0}
 
@@ -461,14 +486,21 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
             prof["update"] += time.perf_counter() - b
 
     elapsed, _ = timed(go, dist, dev)
+    per_rank = [p[0] for p in gather_over_ranks([elapsed], device=reduce_dev)]     # every rank's own clock (a straggler must be visible)
     elapsed = max_over_ranks([elapsed], device=reduce_dev)[0]
     n = envs * rollout_len * rollouts
     st = runner.stats
+    ar_ms, ar_bytes = st.get("allreduce_ms"), grad_allreduce_bytes(runner.net)
+    busbw = (2.0 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms) else None
     return {"metric": "A2C end-to-end env steps/sec (policy + sampling + env step + update incl. gradient all-reduce)",
             "value": whole_job_rate(n, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "envs_per_gpu": envs,
             "rollout_len": rollout_len, "rollouts": rollouts, "ms_per_rollout": elapsed / rollouts * 1e3,
             "collect_ms_per_rollout": prof["collect"] / rollouts * 1e3, "update_ms_per_rollout": prof["update"] / rollouts * 1e3,
-            "allreduce_ms_per_update": st.get("allreduce_ms"), "grad_allreduce_bytes": grad_allreduce_bytes(runner.net),
+            "per_rank_elapsed_s": per_rank,
+            "allreduce_ms_per_update": ar_ms, "grad_allreduce_bytes": ar_bytes,
+            "allreduce_busbw_GBps": busbw, "allreduce_busbw_note": "2 (N-1)/N x gradient bytes / all-reduce time of the last update (device "
+            "events around the collective(s)); null at 1 rank.  xGMI ring: 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md)",
+            "allreduce_overlapped_ms": st.get("allreduce_overlapped_ms"), "allreduce_buckets": st.get("allreduce_buckets"),
             "allreduce": ("RCCL (nccl backend), one flat bucket per update" if (world > 1 and args.backend == "nccl")
                           else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
             "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
@@ -543,25 +575,30 @@ def main(argv=None):
 
     E, K, W = args.envs or 4096, args.steps, args.warmup
     env_id_base, _ = shard_for_rank(rank, world, E)   # rank r owns global envs [r*E, (r+1)*E): no env-path collective
-    n_bs, n_ue = args.n_bs, args.n_ue
-    baseline_shape = (n_bs, n_ue) == (N_BS, N_UE)
-    groups = GROUPS if baseline_shape else [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
+    n_bs, n_ue, grid = args.n_bs, args.n_ue, args.grid
+    baseline_shape = (n_bs, n_ue, grid) == (N_BS, N_UE, GRID)
+    groups = GROUPS if (n_bs, n_ue) == (N_BS, N_UE) else [n_ue // 4] * 3 + [n_ue - 3 * (n_ue // 4)]
 
-    def make_env():
-        return BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=GRID, groups=groups, device=dev, seed=SEED, env_id_base=env_id_base)
+    def make_env(g=None):
+        return BatchedMobiEnv(E, nBS=n_bs, nUE=n_ue, grid_n=g or grid, groups=groups, device=dev, seed=SEED, env_id_base=env_id_base)
 
     # Order: the other launch forms first (they bring clocks and caches up), then the headline behind its own scratch-env
     # pre-warm, and the A2C leg LAST: measured on one box, a 20-step headline region ran at 5.6e8 env-steps/s when the A2C leg
     # (TunableOp, BLAS handles, a captured graph, a side stream, several GB of buffers) came before it and at 6.5-6.7e8 when it
     # comes after.  Every measurement has its own env, its own W warm-up steps and its own bracketed timed region.
-    alt = {}
+    alt, grids = {}, {}
     if not args.no_alt:                                # secondary: the other launch forms on the same box, same K / W
-        for other in (("eager", "many", "graph", "seq") if world == 1 else ("seq",)):   # N > 1: the one-kernel-per-step form only
+        for other in (("eager", "many", "manypk", "graph", "seq") if world == 1 else ("seq",)):   # N > 1: the one-kernel-per-step form only
             if other != args.launch:
-                el, gm = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
+                el, gm, info = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
                 alt[other] = {"value": whole_job_rate(E * K, world, el), "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
-                              "us_per_step_gpu": gm * 1e3 / K}
-    elapsed, gpu_ms = measure_env(args, make_env(), args.launch, K, W, dist, dev, reduce_dev, rank, scratch=make_env())
+                              "us_per_step_gpu": gm * 1e3 / K, "kernel": (info["kernels"] or [None])[0]}
+        if world == 1 and grid == GRID:                # "G=100 ... also report G=200" (the class default, mobile_env.py:37)
+            el, gm, info = measure_env(args, make_env(200), args.launch, K, W, dist, dev, reduce_dev, rank)
+            grids["200"] = {"value": whole_job_rate(E * K, world, el), "unit": "env-steps/s", "us_per_step_gpu": gm * 1e3 / K,
+                            "launch": args.launch, "note": "same workload on a 200 x 200 grid: compact outputs do not grow with G (the dense "
+                            "observation would: 800 000 B per env-step instead of 200 000)"}
+    elapsed, gpu_ms, info = measure_env(args, make_env(), args.launch, K, W, dist, dev, reduce_dev, rank, scratch=make_env())
     a2c = None
     if not args.no_a2c and baseline_shape:
         try:
@@ -573,14 +610,21 @@ def main(argv=None):
         per_step_s = gpu_ms * 1e-3 / K   # average per-step device time (HIP events on the launch stream around the timed region)
         b_step = algorithmic_bytes_per_env_step(n_ue, n_bs, len(groups))
         achieved = b_step * E / per_step_s / 1e9
-        many = args.launch == "many"
-        kernel = STEP_KERNEL.replace("false>", "true>") if many else STEP_KERNEL
+        many = args.launch in ("many", "manypk")
+        kernel = (info["kernels"] or ["?"])[0]                  # the instantiation the timed region launched (library's launch census)
         spl = min(CHUNK, K) if many else 1                      # steps one launch of the dominant kernel processes
-        cnt = committed_counters(E, kernel) if baseline_shape else None
+        cnt = committed_counters(E, n_bs, n_ue, kernel)
+        n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "traffic_source": None,
-                "kernel": kernel if baseline_shape else "env kernel of this shape (secondary measurement)",
+                "achieved_is": "NOMINAL: SURVEY 8(d)'s algorithmic bytes per env-step x env-steps per launch / launch time, as the bench "
+                               "contract defines it -- not bytes that crossed the bus (see moved_*; a multi-step launch reads and writes "
+                               "the state once per launch, not once per step)",
+                "algorithmic_GBps": achieved,
+                "traffic": None, "traffic_source": None, "moved_bytes_per_step": None, "moved_GBps": None, "moved_frac": None,
+                "bound_actual": "valu_issue", "valu_issue_frac": None,
+                "kernel": kernel, "kernels_launched_in_timed_region": info["kernels"],
                 "steps_per_launch": spl,
+                "algorithmic_bytes_per_env_step": b_step,
                 "algorithmic_bytes_per_launch": b_step * E * spl,
                 "avg_launch_us": per_step_s * 1e6 * spl,
                 "avg_step_us": per_step_s * 1e6,
@@ -593,30 +637,43 @@ def main(argv=None):
             scale = spl / float(cnt["steps_per_launch"])
             roof["traffic"] = int((2 * int(cnt["fetch_size_bytes_raw"]) + int(cnt["write_size_bytes_raw"])) * scale)
             roof["traffic_over_algorithmic"] = roof["traffic"] / float(b_step * E * spl)
-            roof["traffic_source"] = ("profiles/traffic_current.json: committed rocprofv3 PMC passes of this kernel (FETCH_SIZE x2 "
-                                      "gfx950 correction + WRITE_SIZE), NOT measured by this run")
-            n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            roof["traffic_source"] = ("profiles/traffic_current.json (%s): committed rocprofv3 PMC passes of this kernel at this batch size "
+                                      "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), NOT measured by this run" % cnt.get("source", "?"))
+            roof["moved_bytes_per_step"] = roof["traffic"] / float(spl)
+            roof["moved_GBps"] = roof["moved_bytes_per_step"] / per_step_s / 1e9
+            roof["moved_frac"] = roof["moved_GBps"] / HBM_PEAK_GBPS
             roof["valu_issue_frac"] = (cnt["valu_insts_per_launch"] * scale) / (n_simd * SIMD_ISSUE_HZ * per_step_s * spl)
             roof["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed profile) / (%d SIMDs x 0.6 G wave-instr/s) / measured "
                                        "launch time: the roof that actually bounds this float64-ALU kernel" % n_simd)
+            roof["rocprof_avg_kernel_us"] = cnt.get("rocprof_avg_kernel_ns", 0) / 1e3
+        if world > 1:                                   # per GPU above (rank 0's events, MAX over ranks); the node moves world x that
+            roof["per"] = "GPU"
+            roof["whole_node_algorithmic_GBps"] = achieved * world
+            roof["whole_node_peak_GBps"] = HBM_PEAK_GBPS * world
+        form = {"seq": "one kernel per step, launches issued by one C call (uavenv_step_seq) per <=100 steps",
+                "graph": "one kernel per step, hipGraph replay of <=100-step chunks",
+                "eager": "one kernel launch per step from Python",
+                "many": "OPEN-LOOP action tape through uavenv_step_many: <=100 consecutive steps per launch, state carried in registers between "
+                        "them, all nine outputs of every step written (a policy in the loop gets single_step_launch_value)",
+                "manypk": "OPEN-LOOP action tape through uavenv_step_many_packed: as `many`, outputs of every step written as packed "
+                          "records (12 B per walker, 8 B per UAV, 16 B per env)"}[args.launch]
         line = {
             "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
             "unit": "env-steps/s", "n_gpus": n_ranks, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "launch": args.launch, "prewarm_steps_on_scratch_env": PREWARM_STEPS,
-            "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=100, HIP step(), compact outputs, "
-                                   "on-device Philox, %s" % (E, n_bs, n_ue, ",".join(str(g) for g in groups),
-                                                             {"seq": "one kernel per step, launches issued by one C call (uavenv_step_seq) per <=100 steps",
-                                                              "graph": "one kernel per step, hipGraph replay of <=100-step chunks",
-                                                              "eager": "one kernel launch per step from Python",
-                                                              "many": "uavenv_step_many: <=100 consecutive steps per launch, state carried in registers between them, all nine outputs of every step written"}[args.launch]),
-                       "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": GRID, "parallelism": "env-shard x%d" % world},
+            "config": {"workload": "%d batched envs/GPU, %d UAV x %d UE (groups %s), G=%d, HIP step(), compact outputs, "
+                                   "on-device Philox, %s" % (E, n_bs, n_ue, ",".join(str(g) for g in groups), grid, form),
+                       "envs_per_gpu": E, "n_bs": n_bs, "n_ue": n_ue, "grid": grid, "parallelism": "env-shard x%d" % world},
+            "per_rank_elapsed_s": info["per_rank_elapsed_s"], "per_rank_gpu_ms": info["per_rank_gpu_ms"],
             "roofline": roof,
         }
         if alt:
             line["other_launch_forms"] = alt
             if "seq" in alt:             # one kernel launch per step (what a closed-loop caller, e.g. the A2C rollout, gets)
                 line["single_step_launch_value"] = alt["seq"]["value"]
+        if grids:
+            line["other_grids"] = grids
         if a2c is not None:
             line["a2c"] = a2c
         if world == 1 and not args.no_cpu_baseline and baseline_shape:

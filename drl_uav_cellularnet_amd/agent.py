@@ -203,6 +203,24 @@ def sample_actions(prob, generator=None, uniforms=None):
 
 
 _TUNABLE_DONE = False
+_TUNABLE_DIR = None
+
+
+def freeze_gemm_tuning():
+    """Stop TunableOp from TUNING further shapes (the picks already made or loaded stay in use): called by A2CRunner after its
+    eager warm-up pass, so that no later GEMM of the host application -- or of a graph capture -- triggers a timing run, and two
+    processes that warmed up on the same shapes keep the same picks."""
+    if _TUNABLE_DONE:
+        import torch.cuda.tunable as tun
+
+        tun.tuning_enable(False)
+
+
+def _remove_tunable_dir():
+    import shutil
+
+    if _TUNABLE_DIR:
+        shutil.rmtree(_TUNABLE_DIR, ignore_errors=True)
 
 
 def enable_gemm_tuning(max_ms=400):
@@ -211,11 +229,15 @@ def enable_gemm_tuning(max_ms=400):
     (profiles/r02f_gemm_tunableop.txt: the update's seven large GEMMs 7.3 -> 5.2 ms).  Picks for the BASELINE config 3 shapes ship
     in data/tunableop_gfx950.csv (valid for this image's ROCm / hipBLASLt build: TunableOp checks the versions recorded in the file
     and ignores it otherwise); any other shape is tuned at first use for at most ``max_ms``, outside graph capture (the rollout graph
-    is captured after an eager warm-up pass).  Once per process; a no-op without a GPU or without torch.cuda.tunable."""
-    global _TUNABLE_DONE
+    is captured after an eager warm-up pass).  Once per process; a no-op without a GPU or without torch.cuda.tunable.
+    OPT-IN (A2CRunner(tune_gemms=True); bench.py and tools/train_a2c.py ask for it): it switches TunableOp on for the whole process.
+    Bit-identical checkpoint resume holds for the shipped shapes (their picks come from the file); a shape tuned at first use may get
+    another pick in another process."""
+    global _TUNABLE_DONE, _TUNABLE_DIR
     if _TUNABLE_DONE or not torch.cuda.is_available():
         return _TUNABLE_DONE
     try:
+        import atexit
         import os
         import shutil
         import tempfile
@@ -223,7 +245,9 @@ def enable_gemm_tuning(max_ms=400):
         import torch.cuda.tunable as tun
 
         src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tunableop_gfx950.csv")
-        dst = os.path.join(tempfile.mkdtemp(prefix="uavagent_tunable_"), "tunableop_results.csv")   # TunableOp rewrites its file at exit
+        _TUNABLE_DIR = tempfile.mkdtemp(prefix="uavagent_tunable_")
+        atexit.register(_remove_tunable_dir)
+        dst = os.path.join(_TUNABLE_DIR, "tunableop_results.csv")   # TunableOp rewrites its file at exit
         if os.path.isfile(src):
             shutil.copyfile(src, dst)
         tun.set_filename(dst)
@@ -283,7 +307,7 @@ class A2CRunner:
     around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=True):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False

@@ -409,6 +409,8 @@ class BatchedMobiEnv:
         out = torch.empty((N, G, G), dtype=dtype, device=self.device)
         bptr = None
         if bs_xy is not None:
+            if not isinstance(bs_xy, torch.Tensor):
+                bs_xy = np.array(bs_xy, dtype=np.int32)            # (a copy: a read-only broadcast view would make torch.as_tensor warn)
             b = torch.as_tensor(bs_xy).to(device=self.device, dtype=torch.int32).contiguous()
             if b.numel() != N * B * 2:
                 raise ValueError("bs_xy must be [n_envs, nBS, 2]")

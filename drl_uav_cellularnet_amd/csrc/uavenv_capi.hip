@@ -6,9 +6,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/uavenv.h"
 #include "uavenv_kernels.h"
@@ -33,6 +35,10 @@ struct uavenv {
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
     const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
+    struct RotPlan { int n_steps; int n_launches; long long slots; int4 *dev; };   // rotation schedules built so far (one per n_steps)
+    std::vector<RotPlan> *rot_plans;
+    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 whenever a schedule exists (tests)
+    long long rot_slots;  // UAVENV_ROTATE_SLOTS (tests: pretend the device has this many SIMDs), else n_simd
     char *scratch_out;  // multi-pass handles, uavenv_step_many_packed: one step's nine output arrays (allocated on first use)
     int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
@@ -161,10 +167,15 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     h->cfg = *cfg; h->N = n_envs; h->device = device; h->seed = seed; h->env_id_base = env_id_base;
     h->force_pin = -1;
     if (const char *f = std::getenv("UAVENV_FORCE_PIN")) h->force_pin = (f[0] == '1') ? 1 : 0;
+    h->rotate = -1;
+    if (const char *f = std::getenv("UAVENV_ROTATE")) h->rotate = (f[0] == '1') ? 1 : 0;
+    h->rot_plans = new (std::nothrow) std::vector<uavenv::RotPlan>();
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
         h->n_simd = 4ll * cus;
+        h->rot_slots = h->n_simd;
+        if (const char *f = std::getenv("UAVENV_ROTATE_SLOTS")) { const long long v = std::atoll(f); if (v > 0) h->rot_slots = v; }
     }
     const size_t U = (size_t)cfg->n_ue, B = (size_t)cfg->n_bs;
     const size_t W64 = (U + 63) / 64;
@@ -264,6 +275,10 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
     if (h->scratch_out) (void)hipFree(h->scratch_out);
+    if (h->rot_plans) {
+        for (auto &pl : *h->rot_plans) (void)hipFree(pl.dev);
+        delete h->rot_plans;
+    }
     delete h;
 }
 
@@ -359,11 +374,12 @@ extern "C" void uavenv_debug_variant_reset(void) {
 
 // MANY_: 0 = one step / reset / tick batch per launch, 1 = uavenv_step_many (nine output arrays), 2 = uavenv_step_many_packed
 template <int MODE, int MANY_ = 0>
-static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s) {
+static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s, long long launch_waves = 0) {
     constexpr bool MANY = MANY_ != 0, PKO = MANY_ == 2;
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
     const long long waves = (p.N + p.epw - 1) / p.epw;
-    const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    // (a launch of a rotation schedule has `launch_waves` slots instead of one wavefront per env-wavefront; p.sched says who does what)
+    const unsigned grid = (unsigned)(((launch_waves > 0 ? launch_waves : waves) + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
     // leading scalar arguments of the packed kernels: delivered in SGPRs at wave launch (kernarg preload), see
     // env_kernel_packed.  The slab base replaces the 19 per-field pointers (state_layout.h).
@@ -497,6 +513,110 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
     return r;
 }
 
+// ---- rotation schedule for multi-step launches ----------------------------------------------------------------------------------
+// A batch of W env-wavefronts on S SIMDs with S < W < 2 S leaves W - S SIMDs with two wavefronts for the whole launch; they set its
+// time and the others idle half of it (BASELINE's 4096 envs x 20 UEs: 1366 wavefronts on 1024 SIMDs).  The W x T wavefront-steps fit
+// S slots in M = ceil(W T / S) step-times (McNaughton's wrap-around rule: fill slot after slot, a job that does not fit is split, its
+// LAST steps at the end of this slot, its FIRST steps at the start of the next).  Cutting every slot's timeline at D = ceil(M / (M - T))
+// common boundaries gives D launches of S wavefronts, one per SIMD, each working through at most two segments (env-wavefront, first
+// step, steps); a split job's two parts are at least M - T step-times apart, hence in different launches, so stream order is all the
+// synchronisation needed.  Measured bound before building it (profiles/r03a_many_ab_rotation_bound.json): 4 launches of 1024
+// wavefronts x 34 steps take 396 us against 431 us for 1366 wavefronts x 100 steps.
+// Returns the cached / newly built plan, or nullptr when rotation does not apply (then the plain launch runs).
+static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
+    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < (h->rotate == 1 ? 2 : 8)) return nullptr;
+    const long long W = (h->N + h->kp.epw - 1) / h->kp.epw, S = h->rot_slots;
+    if (W <= S || W >= 2 * S) return nullptr;
+    for (const auto &pl : *h->rot_plans) if (pl.n_steps == T) return pl.dev ? &pl : nullptr;
+    auto remember = [&](int D, int4 *dev) -> const uavenv::RotPlan * {
+        h->rot_plans->push_back(uavenv::RotPlan{T, D, S, dev});
+        return dev ? &h->rot_plans->back() : nullptr;
+    };
+    const long long M = (W * T + S - 1) / S;                       // makespan in step-times
+    if (M - T < 1) return remember(0, nullptr);
+    const long long D = (M + (M - T) - 1) / (M - T);              // launches: windows no longer than M - T
+    // Automatic use only where it pays: a single wavefront per SIMD runs a step in ~0.64 of the time two co-resident ones take
+    // (2.77 vs 4.31 us at 4096 envs), every extra launch costs ~8 us of load / store / launch phases: 1.2 <= W / S <= 1.45.
+    if (h->rotate != 1 && (D > 6 || 100 * W > 145 * S)) return remember(0, nullptr);
+    if (D > 64) return remember(0, nullptr);
+    std::vector<long long> bound((size_t)D + 1);
+    for (long long k = 0; k <= D; ++k) bound[(size_t)k] = k * M / D;
+    struct Piece { int ew, t0, nt; };
+    std::vector<std::vector<Piece>> cell((size_t)(D * S));        // [launch][slot] -> pieces in time order
+    std::vector<int> last_launch((size_t)W, -1), next_step((size_t)W, 0);
+    bool ok = true;
+    auto place = [&](long long slot, long long time, int ew, int step, int len) {   // a run of `len` steps of job ew at `time` on `slot`
+        while (len > 0 && ok) {
+            long long k = 0;
+            while (bound[(size_t)k + 1] <= time) ++k;                               // window of `time`
+            const int n = (int)std::min<long long>(len, bound[(size_t)k + 1] - time);
+            cell[(size_t)(k * S + slot)].push_back(Piece{ew, step, n});
+            time += n; step += n; len -= n;
+        }
+    };
+    {   // McNaughton fill.  The FIRST steps of a split job go to the next slot's start, so jobs are placed in two passes per slot.
+        long long slot = 0, t = 0;
+        for (long long j = 0; j < W && ok; ++j) {
+            if (slot >= S) { ok = false; break; }
+            if (t + T <= M) {
+                place(slot, t, (int)j, 0, T);
+                t += T;
+                if (t == M) { ++slot; t = 0; }
+            } else {
+                const int a = (int)(M - t);                                         // steps that still fit here: the job's LAST a steps
+                if (slot + 1 >= S) { ok = false; break; }
+                place(slot + 1, 0, (int)j, 0, T - a);
+                place(slot, t, (int)j, T - a, a);
+                ++slot; t = T - a;
+            }
+        }
+    }
+    // Verify what the argument above promises: every job's steps 0..T-1 exactly once, in launches that strictly increase with the
+    // step index; at most two pieces per (launch, slot).
+    for (long long k = 0; k < D && ok; ++k)
+        for (long long sl = 0; sl < S && ok; ++sl) {
+            const auto &c = cell[(size_t)(k * S + sl)];
+            if (c.size() > 2) ok = false;
+            for (const Piece &pc : c) {
+                if (pc.t0 != next_step[(size_t)pc.ew] || (int)k <= last_launch[(size_t)pc.ew]) { ok = false; break; }
+                next_step[(size_t)pc.ew] = pc.t0 + pc.nt;
+                last_launch[(size_t)pc.ew] = (int)k;
+            }
+        }
+    for (long long j = 0; j < W && ok; ++j) if (next_step[(size_t)j] != T) ok = false;
+    if (!ok) return remember(0, nullptr);
+    std::vector<int4> table((size_t)(D * S * 2), int4{0, 0, 0, 0});
+    for (size_t i = 0; i < cell.size(); ++i)
+        for (size_t q = 0; q < cell[i].size(); ++q) table[i * 2 + q] = int4{cell[i][q].ew, cell[i][q].t0, cell[i][q].nt, 0};
+    int4 *dev = nullptr;
+    if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
+    if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }
+    return remember((int)D, dev);
+}
+
+// Test hook: the schedule uavenv_step_many would use for n_steps (0 launches = plain launch).
+extern "C" int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots) {
+    if (!h || n_steps < 0) return fail(UAVENV_E_INVALID, "debug_rotation_info: null handle or negative n_steps");
+    DeviceGuard guard(h->device);
+    const uavenv::RotPlan *pl = rotation_plan(h, n_steps);
+    if (n_launches) *n_launches = pl ? pl->n_launches : 0;
+    if (slots) *slots = pl ? pl->slots : 0;
+    return UAVENV_OK;
+}
+
+template <int MANY_>
+static int launch_many(uavenv_t *h, KParams &p, int n_steps, hipStream_t s) {
+    if (const uavenv::RotPlan *pl = rotation_plan(h, n_steps)) {       // (first use of this n_steps: builds + uploads the table, synchronously)
+        for (int k = 0; k < pl->n_launches; ++k) {
+            p.sched = pl->dev + (size_t)k * (size_t)pl->slots * 2;
+            if (int rc = launch_env<MODE_STEP, MANY_>(h, p, s, pl->slots)) return rc;
+        }
+        return UAVENV_OK;
+    }
+    p.sched = nullptr;
+    return launch_env<MODE_STEP, MANY_>(h, p, s);
+}
+
 extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream) {
     if (!h || !actions_dev || n_steps < 0) return fail(UAVENV_E_INVALID, "step_many: null handle / actions or negative n_steps");
     if (n_steps == 0) return UAVENV_OK;
@@ -505,7 +625,7 @@ extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_s
         KParams p = h->kp;
         fill_call(p, nullptr, out);
         p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
-        return launch_env<MODE_STEP, 1>(h, p, (hipStream_t)stream);
+        return launch_many<1>(h, p, n_steps, (hipStream_t)stream);
     }
     // multi-pass handles (n_ue > 64): one single-step launch per step on the same stream, each writing its own output block
     for (int t = 0; t < n_steps; ++t) {
@@ -569,7 +689,7 @@ extern "C" int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, 
         fill_call(p, nullptr, nullptr);
         p.pk = packed_block(*out, 0, N, U, B);
         p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
-        return launch_env<MODE_STEP, 2>(h, p, (hipStream_t)stream);
+        return launch_many<2>(h, p, n_steps, (hipStream_t)stream);
     }
     // multi-pass handles (n_ue > 64): per step one single-step launch into the scratch block, then the packing kernel
     UavEnvOut so;

@@ -109,6 +109,8 @@ struct KParams {
     OutPtrs out;
     unsigned long long *dbg;   // diagnostic builds only (UAVENV_STAMPS): [waves][8] s_memtime stamps
     OutPacked pk;              // uavenv_step_many_packed (PKO kernels): packed output records instead of `out`
+    const int4 *sched;         // multi-step launches: work descriptors [launch waves][2] {env-wavefront, first step, steps, -} of a
+                               // rotation schedule (uavenv_capi.hip: rotation_plan), or null = wave w runs env-wavefront w, all steps
 };
 
 struct InitParams {
@@ -606,6 +608,24 @@ __device__ __forceinline__ void out_next_step(OutPtrs &o, long long N, int U, in
     if (UAV_OUT64(o.reward_f64)) o.reward_f64 += N;
 }
 
+// A segment of a rotation schedule starts at step t0: move every output pointer on by t0 blocks (uniform, once per segment).
+template <bool FAST>
+__device__ __forceinline__ void out_skip_steps(OutPtrs &o, long long t0, long long N, int U, int B) {
+    const long long n = t0 * N, nu = n * U, nb2 = n * B * 2;
+    if (UAV_OUT(o.reward)) o.reward += n;
+    if (UAV_OUT(o.done)) o.done += n;
+    if (UAV_OUT(o.mean_sinr)) o.mean_sinr += n;
+    if (UAV_OUT(o.n_out)) o.n_out += n;
+    if (UAV_OUT(o.ue_xy)) o.ue_xy += 2 * nu;
+    if (UAV_OUT(o.bs_xy)) o.bs_xy += nb2;
+    if (UAV_OUT(o.serving)) o.serving += nu;
+    if (UAV_OUT(o.cur_sinr)) o.cur_sinr += nu;
+    if (UAV_OUT(o.step_n)) o.step_n += n;
+    if (UAV_OUT64(o.cur_sinr_f64)) o.cur_sinr_f64 += nu;
+    if (UAV_OUT64(o.mean_sinr_f64)) o.mean_sinr_f64 += n;
+    if (UAV_OUT64(o.reward_f64)) o.reward_f64 += n;
+}
+
 // One step's per-env outputs as ONE 16-byte record (PKO kernels): the arithmetic of env_finish's step branch
 // (mobile_env.py:163-189; channel.py:216), `step_n` = the count BEFORE this step.
 __device__ __forceinline__ void env_finish_packed(const KParams &p, StepOut *dst, uint32_t e, int step_n, double sum_cur, int n_outage) {
@@ -676,34 +696,29 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // computes) and writes block t of every output array.  Exactly the arithmetic of p.n_ticks single-step launches, so results
 // are bit-identical (tests/test_step_many_gpu.py); what disappears is the per-step launch, kernarg fetch, state load round
 // trip and state store, i.e. the fixed ~5.8 us a 4096-env launch spends outside its arithmetic.
-// PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
-                                                                              const int8_t *gid_of_u, long long N, int U, int EPW,
-                                                                              int Gr, int B_rt, int lane_magic, const KParams p) {
-    static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
-    static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
-    // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
-    // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
-    // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
-    __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
+// The kernel proper: `ew` = the env-wavefront this wavefront hosts (envs ew*EPW .. ew*EPW+EPW-1), `t0` / `nt` = first step and
+// number of steps (multi-step launches; a plain launch runs env-wavefront = hardware wavefront and all of p.n_ticks).
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, bool PKO>
+__device__ __forceinline__ void env_packed_body(char *blob, const long long *actions, const int8_t *gid_of_u, long long N, int U, int EPW,
+                                                int Gr, int B_rt, int lane_magic, const KParams &p, int (*s_bs)[kMaxEpw][2 * kMaxBs],
+                                                const int wave, const long long ew, const int t0, const int nt) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = uav_count<BT, FAST>(B_rt);
     const StatePtrs st = state_from_blob(blob, N, U, B, Gr);
     const int slot = (int)lane_div((uint32_t)lane, (uint32_t)lane_magic);   // lane / U (intdiv.h); lanes >= EPW*U are not live
     const int base = slot * U;   // first lane of my slot
     const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
-    long long e = ((long long)blockIdx.x * kWavesPerBlock + wave) * EPW + slot;
+    long long e = ew * EPW + slot;
     bool live = (lane < EPW * U) && (e < N);
     if (is_reset(MODE)) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
     if (__ballot(live) == 0ull) return;
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
     const unsigned long long slot_mask = ((U >= 64) ? ~0ull : ((1ull << U) - 1ull)) << base;
-    const int n_ticks = (MODE == MODE_WARMUP || MANY) ? p.n_ticks : 1;   // iterations of the tick / step loop below
+    const int n_ticks = MANY ? nt : ((MODE == MODE_WARMUP) ? p.n_ticks : 1);   // iterations of the tick / step loop below
+    if (MANY) actions += (long long)t0 * N;          // row of this segment's first step
     int *bs_row = s_bs[wave][slot];
     const int u = ul;
     const long long iu = e * U + (live ? u : 0);
@@ -792,6 +807,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     unsigned long long ob = 0ull;
     OutPtrs om = p.out;                                // MANY: the current step's output blocks (dead code otherwise)
     OutPacked ok = p.pk;                               // PKO: the current step's record blocks
+    if (MANY && !PKO) out_skip_steps<FAST>(om, t0, N, U, B);
+    if (PKO) { ok.walker += (long long)t0 * N * U; ok.bs_xy += (long long)t0 * N * B; ok.env += (long long)t0 * N; }
     for (int it = 0; it < n_ticks; ++it) {
         long long act_next = 0;
         if (MANY) {                                    // prefetch the next step's action: its round trip hides behind this step
@@ -970,6 +987,46 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = ts5; d[6] = ts6; d[7] = ts7;
     }
 #endif
+}
+
+// PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
+                                                                              const int8_t *gid_of_u, long long N, int U, int EPW,
+                                                                              int Gr, int B_rt, int lane_magic, const KParams p) {
+    static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
+    static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
+    // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
+    // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
+    // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
+    __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave;     // this wavefront's index in the launch (uniform)
+    if (!MANY) {
+        env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1);
+    } else {
+        // Multi-step launch.  Plain: wavefront w hosts env-wavefront w for all p.n_ticks steps.  Rotation schedule (p.sched,
+        // uavenv_capi.hip: rotation_plan): this wavefront is a SLOT that works through up to two segments, each a run of consecutive
+        // steps of one env-wavefront: state loaded, nt steps, state stored.  Segments of one env-wavefront never share a launch, so
+        // the stream order of the launches is the only synchronisation the schedule needs.
+        // (Two inlined copies of the body rather than a loop around one: with the loop hipcc allocated 330 VGPRs for the pinned
+        // kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
+        const int4 *sched = p.sched;
+        int ew = (int)gw, t0 = 0, nt = p.n_ticks;
+        if (sched != nullptr) {
+            const int4 d = sched[gw * 2];                                     // uniform address
+            ew = __builtin_amdgcn_readfirstlane(d.x); t0 = __builtin_amdgcn_readfirstlane(d.y); nt = __builtin_amdgcn_readfirstlane(d.z);
+        }
+        if (nt > 0) env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
+        if (sched != nullptr) {
+            const int4 d = sched[gw * 2 + 1];
+            ew = __builtin_amdgcn_readfirstlane(d.x); t0 = __builtin_amdgcn_readfirstlane(d.y); nt = __builtin_amdgcn_readfirstlane(d.z);
+            if (nt > 0) {
+                __builtin_amdgcn_wave_barrier();                               // (the first segment's reads of the LDS row are done)
+                env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
+            }
+        }
+    }
 }
 
 // ================================================================================================

@@ -32,3 +32,19 @@ def max_over_ranks(values, device=None):
 def whole_job_rate(units_per_rank, world_size, seconds):
     """Whole-job throughput: units processed by ALL ranks / the slowest rank's time."""
     return float(units_per_rank) * int(world_size) / float(seconds)
+
+
+def gather_over_ranks(values, device=None):
+    """[[values of rank 0], [values of rank 1], ...] on every rank (one all-gather of a small float64 tensor; [[values]] when
+    torch.distributed is not initialised).  bench.py prints every rank's own elapsed time beside the MAX it reports, so that a
+    straggler is visible in the line instead of hidden in the maximum."""
+    import torch
+
+    dist = torch.distributed
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()):
+        return [vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o] for o in out]

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define UAVENV_ABI_VERSION 4   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
-                                * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census) */
+                                * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -199,6 +199,12 @@ int uavenv_lean_math_eval(int op, const double *a_dev, const double *b_dev, doub
 int uavenv_debug_variant_count(void);
 int uavenv_debug_variant_info(int i, char *name, size_t name_len, int *selectable, long long *launches);
 void uavenv_debug_variant_reset(void);
+
+/* Test hook: how uavenv_step_many / uavenv_step_many_packed would run n_steps on this handle: *n_launches = 0 for the plain single
+ * launch, else the number of launches of the rotation schedule and *slots wavefronts per launch.  Environment,
+ * read once in uavenv_create: UAVENV_ROTATE=0 never rotate, =1 rotate whenever a valid schedule exists; UAVENV_ROTATE_SLOTS=k
+ * plan as if the device had k SIMDs (lets small batches exercise the schedule). */
+int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots);
 
 /* Philox4x32-10 of one counter/key on the HOST (known-answer tests of the generator the kernels use). */
 void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -66,13 +66,19 @@ def test_bench_sized_batches_match_the_oracle_on_windows(n_envs):
             _compare(env.out, o.step(a_np[k:k + WIN]), k, "step %d" % t)
 
 
-@pytest.mark.parametrize("n", [4096, 8192, 65536])
-def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n):
-    """4096 envs: the pinned multi-step kernel; 8192 / 65536: the UNPINNED one (more than two wavefronts per SIMD), the
-    instantiation behind DESIGN section 5's 65 536-env `step_many` figure."""
+@pytest.mark.parametrize("n,rotate", [(4096, None), (4096, "0"), (8192, None), (65536, None)],
+                         ids=["4096_auto_rotation", "4096_plain_launch", "8192", "65536"])
+def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n, rotate, monkeypatch):
+    """4096 envs: the pinned multi-step kernel, once as the library runs it by default (1366 wavefronts on 1024 SIMDs: the rotation
+    schedule, 4 launches of 1024 wavefronts) and once as ONE plain launch (UAVENV_ROTATE=0); 8192 / 65536: the UNPINNED kernel (more
+    than two wavefronts per SIMD), the instantiation behind DESIGN section 5's 65 536-env `step_many` figure."""
     torch = _torch()
+    import ctypes as C
+
     from drl_uav_cellularnet_amd import BatchedMobiEnv, _capi
 
+    if rotate is not None:
+        monkeypatch.setenv("UAVENV_ROTATE", rotate)
     census0 = {name: cnt for name, _, cnt in _capi.launch_census()}
     env_m = BatchedMobiEnv(n, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], seed=0x5EED)
     env_g = env_m.clone()
@@ -80,6 +86,10 @@ def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n):
     gen = torch.Generator().manual_seed(99)
     tape = torch.randint(0, 625, (STEPS, n), generator=gen, dtype=torch.int64)
     dev_tape = tape.to(env_m.device)
+    nl = C.c_int(-1)
+    assert env_m._lib.uavenv_debug_rotation_info(env_m._h, STEPS, C.byref(nl), None) == 0
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:          # (MI355X: 1024 SIMDs)
+        assert (nl.value > 0) == (n == 4096 and rotate is None), nl.value
     many = env_m.step_many(dev_tape)
     g = env_g.capture_steps(dev_tape)
     g.replay()
@@ -93,7 +103,7 @@ def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n):
                 _compare(env_g.out, want, k, "graph replay, last step")
     assert np.array_equal(env_m.get_state(), env_g.get_state())
     ran = [name for name, _, cnt in _capi.launch_census() if cnt > census0[name] and "MANY=1" in name]
-    assert ran == ["env_kernel_packed<BT=4, STEP, PLC=1, FAST=1, PIN=%d, MANY=1>" % (1 if n == 4096 else 0)], ran
+    assert ran == ["env_kernel_packed<BT=4, STEP, PLC=1, FAST=1, PIN=%d, MANY=1, PKO=0>" % (1 if n == 4096 else 0)], ran
 
 
 @pytest.mark.parametrize("n_envs", [8192])

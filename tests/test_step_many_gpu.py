@@ -96,6 +96,60 @@ def test_step_many_packed_unpacks_to_exactly_what_step_many_returns(shape, pin, 
         assert torch.equal(got2[k], want[k]), k
 
 
+# (n_envs, n_bs, n_ue, T, slots): W = ceil(n_envs / envs per wavefront) env-wavefronts planned onto `slots` pretend-SIMDs
+ROT_SHAPES = [(100, 4, 20, 7, 24), (100, 4, 20, 50, 26), (301, 4, 20, 33, 80), (50, 4, 40, 9, 37), (33, 3, 20, 6, 8), (20, 8, 20, 5, 5),
+              (10, 16, 60, 6, 7), (64, 4, 20, 100, 16)]
+
+
+@pytest.mark.parametrize("packed_out", [False, True], ids=["nine_arrays", "packed_records"])
+@pytest.mark.parametrize("shape", ROT_SHAPES, ids=lambda s: "%denv_%dx%d_T%d_S%d" % s)
+def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, monkeypatch):
+    """A multi-step call on S < W < 2 S wavefronts is run as several launches of S wavefronts, each working through segments
+    (env-wavefront, first step, steps) of a wrap-around schedule (csrc/uavenv_capi.hip: rotation_plan).  Same steps, same order per
+    env: every output of every step and the final state must equal the single plain launch.  UAVENV_ROTATE_SLOTS makes small batches
+    plan as if the device had that few SIMDs; at BASELINE's 4096 envs the schedule is chosen automatically
+    (tests/test_full_size_parity_gpu.py compares that run with the oracle)."""
+    torch = _torch()
+    import ctypes as C
+
+    n, n_bs, n_ue, T, slots = shape
+    monkeypatch.setenv("UAVENV_ROTATE", "1")
+    monkeypatch.setenv("UAVENV_ROTATE_SLOTS", str(slots))
+    env = _env(n, n_bs, n_ue)
+    monkeypatch.setenv("UAVENV_ROTATE", "0")
+    ref = env.clone()
+    nl, sl = C.c_int(-1), C.c_longlong(-1)
+    assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
+    assert nl.value >= 2 and sl.value == slots, (nl.value, sl.value)            # the rotated handle really rotates ...
+    assert ref._lib.uavenv_debug_rotation_info(ref._h, T, C.byref(nl), C.byref(sl)) == 0 and nl.value == 0    # ... the reference does not
+    act = _actions(torch, env, T, 8)
+    for rep in range(2):                                                        # second call: cached schedule, continues from the stored state
+        if packed_out:
+            got = env.unpack_outputs(env.step_many_packed(act))
+            want = ref.unpack_outputs(ref.step_many_packed(act))
+        else:
+            got, want = env.step_many(act), ref.step_many(act)
+        for k in want:
+            assert torch.equal(got[k], want[k]), "%s differs (call %d)" % (k, rep)
+        assert np.array_equal(env.get_state(), ref.get_state())
+
+
+def test_rotation_is_automatic_at_the_baseline_batch_and_off_elsewhere():
+    torch = _torch()
+    import ctypes as C
+
+    n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    nl, sl = C.c_int(-1), C.c_longlong(-1)
+    for n, T, expect in ((4096, 100, True), (4096, 20, True), (3072, 100, False), (6144, 100, False), (8192, 100, False), (4096, 4, False)):
+        env = _env(n, 4, 20)
+        assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
+        waves = (n + 2) // 3
+        want = expect and (1.2 * n_simd <= waves <= 1.45 * n_simd)              # (a device with another CU count shifts the band)
+        assert (nl.value > 0) == want, (n, T, nl.value, n_simd)
+        if nl.value:
+            assert sl.value == n_simd and 2 <= nl.value <= 6
+
+
 def test_step_many_packed_rejects_bad_arguments():
     torch = _torch()
     import ctypes as C

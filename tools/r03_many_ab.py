@@ -36,7 +36,10 @@ def main():
         return BatchedMobiEnv(n, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], device=dev, seed=0x5EED)
 
     g = torch.Generator().manual_seed(1)
+    os.environ["UAVENV_ROTATE"] = "0"                 # read once per handle, in uavenv_create
     envs = {n: mk(n) for n in (4096, 3072)}
+    os.environ.pop("UAVENV_ROTATE")
+    er = mk(4096)                                      # automatic: the rotation schedule (4 launches of 1024 wavefronts)
     tapes = {(n, T): torch.randint(0, 625, (T, n), generator=g, dtype=torch.int64).to(dev) for n, T in ((4096, 100), (3072, 34), (3072, 100), (4096, 34))}
     e = envs[4096]
     out9 = e.step_many(tapes[(4096, 100)])
@@ -46,9 +49,13 @@ def main():
     o3p = e3.step_many_packed(tapes[(3072, 34)])
     o3l = e3.step_many(tapes[(3072, 100)])
     o4s = e.step_many(tapes[(4096, 34)])
+    outr = er.step_many(tapes[(4096, 100)])
+    outrp = er.step_many_packed(tapes[(4096, 100)])
     legs = {
         "many_9arrays_4096x100": lambda: e.step_many(tapes[(4096, 100)], out=out9, refresh_out=False),
         "many_packed_4096x100": lambda: e.step_many_packed(tapes[(4096, 100)], out=outp),
+        "ROTATED_many_9arrays_4096x100": lambda: er.step_many(tapes[(4096, 100)], out=outr, refresh_out=False),
+        "ROTATED_many_packed_4096x100": lambda: er.step_many_packed(tapes[(4096, 100)], out=outrp),
         "rotation_bound_4x(3072x34)_9arrays": lambda: [e3.step_many(tapes[(3072, 34)], out=o3, refresh_out=False) for _ in range(4)],
         "rotation_bound_4x(3072x34)_packed": lambda: [e3.step_many_packed(tapes[(3072, 34)], out=o3p) for _ in range(4)],
         "many_9arrays_3072x100": lambda: e3.step_many(tapes[(3072, 100)], out=o3l, refresh_out=False),
