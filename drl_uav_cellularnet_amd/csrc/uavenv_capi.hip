@@ -523,6 +523,7 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
 // synchronisation needed.  Measured bound before building it (profiles/r03a_many_ab_rotation_bound.json): 4 launches of 1024
 // wavefronts x 34 steps take 396 us against 431 us for 1366 wavefronts x 100 steps.
 // Returns the cached / newly built plan, or nullptr when rotation does not apply (then the plain launch runs).
+static long long rot_padded_slots(long long S) { return (S + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock; }
 static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
     if (!h->packed || !h->rot_plans || h->rotate == 0 || T < (h->rotate == 1 ? 2 : 8)) return nullptr;
     const long long W = (h->N + h->kp.epw - 1) / h->kp.epw, S = h->rot_slots;
@@ -585,9 +586,16 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
         }
     for (long long j = 0; j < W && ok; ++j) if (next_step[(size_t)j] != T) ok = false;
     if (!ok) return remember(0, nullptr);
-    std::vector<int4> table((size_t)(D * S * 2), int4{0, 0, 0, 0});
-    for (size_t i = 0; i < cell.size(); ++i)
-        for (size_t q = 0; q < cell[i].size(); ++q) table[i * 2 + q] = int4{cell[i][q].ew, cell[i][q].t0, cell[i][q].nt, 0};
+    // One table row per WAVEFRONT of a launch, not per slot: a launch of S slots has ceil(S / kWavesPerBlock) whole workgroups, and the
+    // wavefronts past slot S - 1 of the last one read rows too -- theirs are all-zero (no steps).  (Round 3, first GPU run: with rows
+    // per slot those wavefronts read the next launch's rows, or past the allocation for the last launch: a memory fault at S = 26.)
+    const long long Sp = rot_padded_slots(S);
+    std::vector<int4> table((size_t)(D * Sp * 2), int4{0, 0, 0, 0});
+    for (long long k = 0; k < D; ++k)
+        for (long long sl = 0; sl < S; ++sl) {
+            const auto &c = cell[(size_t)(k * S + sl)];
+            for (size_t q = 0; q < c.size(); ++q) table[(size_t)(k * Sp + sl) * 2 + q] = int4{c[q].ew, c[q].t0, c[q].nt, 0};
+        }
     int4 *dev = nullptr;
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
     if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }
@@ -608,7 +616,7 @@ template <int MANY_>
 static int launch_many(uavenv_t *h, KParams &p, int n_steps, hipStream_t s) {
     if (const uavenv::RotPlan *pl = rotation_plan(h, n_steps)) {       // (first use of this n_steps: builds + uploads the table, synchronously)
         for (int k = 0; k < pl->n_launches; ++k) {
-            p.sched = pl->dev + (size_t)k * (size_t)pl->slots * 2;
+            p.sched = pl->dev + (size_t)k * (size_t)rot_padded_slots(pl->slots) * 2;
             if (int rc = launch_env<MODE_STEP, MANY_>(h, p, s, pl->slots)) return rc;
         }
         return UAVENV_OK;
