@@ -16,7 +16,7 @@ DEPS = [SRC] + [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "
     os.path.join(ROOT, "include", "uavenv.h")]
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libuavenv.so")
-AGENT_SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("agent_kernels.hip", "agent_learner.hip")]
+AGENT_SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("agent_kernels.hip", "agent_learner.hip", "agent_gemm.hip")]
 AGENT_SRC = AGENT_SRCS[0]
 AGENT_DEPS = AGENT_SRCS + [os.path.join(PKG_DIR, "csrc", "agent_common.h"), os.path.join(ROOT, "include", "uavagent.h")]
 AGENT_LIB = os.path.join(LIB_DIR, "libuavagent.so")
