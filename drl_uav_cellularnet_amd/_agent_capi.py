@@ -1,4 +1,4 @@
-"""ctypes binding of libuavagent.so (include/uavagent.h, ABI 2) and the autograd wrapper agent.py uses for CUDA tensors.
+"""ctypes binding of libuavagent.so (include/uavagent.h, ABI 3) and the autograd wrapper agent.py uses for CUDA tensors.
 
 The plain PyTorch forms stay in agent.py as the reference implementations and the CPU path.  Here: thin launch wrappers (no
 allocation beyond outputs, current torch stream) for the first layer, index construction, action sampling and the pieces of
@@ -14,8 +14,9 @@ from . import build as _build
 EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_sum_f32", "uavagent_first_layer_f32",
            "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
-           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1")
-ABI_VERSION = 2
+           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
+           "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32")
+ABI_VERSION = 3
 
 _lib = None
 _P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -44,13 +45,15 @@ def load():
         "uavagent_sparse_rows_sum_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _P],
         "uavagent_first_layer_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _I32, _P],
         "uavagent_obs_indices": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
-        "uavagent_sample_actions": [_P, _P, _I64, _I32, _P, _P, _P],
-        "uavagent_a2c_loss_grad": [_P, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P],
+        "uavagent_sample_actions": [_P, _I64, _P, _I64, _I32, _P, _P, _P],
+        "uavagent_a2c_loss_grad": [_P, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P],
         "uavagent_relu6_bwd": [_P, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P],
         "uavagent_rowdot_f32": [_P, _P, _P, _I64, _I32, _P, _P],
         "uavagent_rows_grad_f32": [_P, _P, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, C.c_size_t, _P],
         "uavagent_nstep_returns_f32": [_P, _P, _I64, _I32, _F, _P, _P],
         "uavagent_rmsprop_tf1": [_P, _P, _P, _I64, _F, _F, _F, _F, _P],
+        "uavagent_gemm_rows_f32": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
+        "uavagent_gemm_tn_f32": [_P, _P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -62,6 +65,10 @@ def load():
     lib.uavagent_relu6_bwd_workspace_bytes.argtypes = [_I32]
     lib.uavagent_rows_grad_workspace_bytes.restype = C.c_size_t
     lib.uavagent_rows_grad_workspace_bytes.argtypes = [_I64, _I32, _I32, _I64]
+    lib.uavagent_gemm_tn_workspace_bytes.restype = C.c_size_t
+    lib.uavagent_gemm_tn_workspace_bytes.argtypes = [_I64, _I32]
+    lib.uavagent_gemm_rows_workspace_bytes.restype = C.c_size_t
+    lib.uavagent_gemm_rows_workspace_bytes.argtypes = [_I64]
     if lib.uavagent_abi_version() != ABI_VERSION:
         raise UavAgentError("libuavagent.so ABI version mismatch")
     _lib = lib
@@ -138,8 +145,9 @@ def obs_indices(obs, grid_n, n_bs, out=None):
 
 
 def sample_actions(logits, uniforms, out=None, prob_out=None):
-    """softmax + inverse-CDF draw per row (main.py:165-169) with caller-supplied uniforms [N]."""
-    _f32c(logits, "logits")
+    """softmax + inverse-CDF draw per row (main.py:165-169) with caller-supplied uniforms [N]; logits may be a column slice of a
+    wider buffer (rows contiguous)."""
+    ld = _row_stride(logits, "logits")
     _f32c(uniforms, "uniforms")
     N, A = logits.shape
     if uniforms.numel() != N:
@@ -147,7 +155,7 @@ def sample_actions(logits, uniforms, out=None, prob_out=None):
     if out is None:
         out = torch.empty((N,), dtype=torch.int64, device=logits.device)
     with torch.cuda.device(logits.device):
-        rc = load().uavagent_sample_actions(_ptr(logits), _ptr(uniforms), N, A, _ptr(out), _ptr(prob_out), _stream(logits.device))
+        rc = load().uavagent_sample_actions(_ptr(logits), ld, _ptr(uniforms), N, A, _ptr(out), _ptr(prob_out), _stream(logits.device))
     _check(rc, "uavagent_sample_actions")
     return out
 
@@ -165,11 +173,12 @@ def loss_grad_workspace(n_actions, device):
 
 
 def a2c_loss_grad(logits, v, target, actions, beta, dv_out, dbias_out, loss_out, ws):
-    """In place: logits <- d a_loss / d logits.  loss_out: float64 [3] = (a_loss, c_loss, sum dv)."""
-    _f32c(logits, "logits")
+    """In place: logits <- d a_loss / d logits.  loss_out: float64 [3] = (a_loss, c_loss, sum dv).  logits may be a column slice of a
+    wider buffer (rows contiguous)."""
+    ld = _row_stride(logits, "logits")
     M, A = logits.shape
     with torch.cuda.device(logits.device):
-        rc = load().uavagent_a2c_loss_grad(_ptr(logits), _ptr(v), _ptr(target), _ptr(actions), M, A, float(beta), _ptr(dv_out),
+        rc = load().uavagent_a2c_loss_grad(_ptr(logits), ld, _ptr(v), _ptr(target), _ptr(actions), M, A, float(beta), _ptr(dv_out),
                                            _ptr(dbias_out), _ptr(loss_out), _ptr(ws), _stream(logits.device))
     _check(rc, "uavagent_a2c_loss_grad")
 
@@ -225,6 +234,59 @@ def rmsprop_tf1(w, ms, g, lr, decay=0.9, eps=1e-10, g_scale=1.0):
         rc = load().uavagent_rmsprop_tf1(_ptr(w), _ptr(ms), _ptr(g), w.numel(), float(lr), float(decay), float(eps), float(g_scale),
                                          _stream(w.device))
     _check(rc, "uavagent_rmsprop_tf1")
+
+
+def _row_stride(t, what):
+    """Row stride (floats) of a 2-D float32 CUDA tensor whose rows are contiguous (a column slice of a wider buffer qualifies)."""
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise UavAgentError("%s must be a float32 CUDA matrix with contiguous rows" % what)
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_rows_workspace(m_rows, device):
+    return torch.empty(max(int(load().uavagent_gemm_rows_workspace_bytes(int(m_rows))), 16), dtype=torch.uint8, device=device)
+
+
+def gemm_rows(a, w, out, w_transposed=False, bias=None, relu6=False, relu6_mask_h=None, colsum_out=None, workspace=None):
+    """out[m, :] = epilogue(a[m, :] @ w) (w [K, N]) or epilogue(a[m, :] @ w.T) (w [N, K], w_transposed): uavagent_gemm_rows_f32,
+    N <= 208.  Epilogue: + bias, relu6; or the relu6-backward mask by the layer's forward output relu6_mask_h.  colsum_out [N]:
+    column sums of out as stored (needs workspace = gemm_rows_workspace(M, device)).  Returns out."""
+    lib = load()
+    M, K = a.shape
+    N = w.shape[0] if w_transposed else w.shape[1]
+    if (w.shape[1] if w_transposed else w.shape[0]) != K or tuple(out.shape) != (M, N):
+        raise UavAgentError("gemm_rows: shapes do not agree: a %s, w %s (transposed=%s), out %s" % (tuple(a.shape), tuple(w.shape), w_transposed, tuple(out.shape)))
+    if bias is not None:
+        _f32c(bias, "bias")
+    h = relu6_mask_h
+    _check(lib.uavagent_gemm_rows_f32(_ptr(a), _row_stride(a, "a"), _ptr(w), _row_stride(w, "w"), 1 if w_transposed else 0, M, K, N,
+                                      _ptr(bias), 1 if relu6 else 0, _ptr(h), 0 if h is None else _row_stride(h, "relu6_mask_h"),
+                                      _ptr(out), _row_stride(out, "out"), _ptr(colsum_out), _ptr(workspace),
+                                      0 if workspace is None else workspace.numel(), _stream(a.device)), "uavagent_gemm_rows_f32")
+    return out
+
+
+def gemm_tn_workspace(m_rows, n_j, device):
+    n = load().uavagent_gemm_tn_workspace_bytes(int(m_rows), int(n_j))
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def gemm_tn(a, b, out, workspace, dbias_out=None):
+    """out[i, j] = sum_m a[m, i] * b[m, j] (the weight gradient x^T dy) and dbias_out[j] = sum_m b[m, j]: uavagent_gemm_tn_f32.
+    a [M, I <= 200] contiguous, b [M, J <= 640] with contiguous rows; deterministic (ordered second pass)."""
+    lib = load()
+    _f32c(a, "a")
+    M, I = a.shape
+    J = b.shape[1]
+    if b.shape[0] != M or tuple(out.shape) != (I, J):
+        raise UavAgentError("gemm_tn: shapes do not agree: a %s, b %s, out %s" % (tuple(a.shape), tuple(b.shape), tuple(out.shape)))
+    if dbias_out is not None:
+        _f32c(dbias_out, "dbias_out")
+        if dbias_out.numel() != J:
+            raise UavAgentError("gemm_tn: dbias_out must have %d elements" % J)
+    _check(lib.uavagent_gemm_tn_f32(_ptr(a), _ptr(b), M, I, J, _row_stride(b, "b"), _ptr(out), _row_stride(out, "out"), _ptr(dbias_out),
+                                    _ptr(workspace), workspace.numel(), _stream(a.device)), "uavagent_gemm_tn_f32")
+    return out
 
 
 _bag_cache = {}

@@ -307,7 +307,7 @@ class A2CRunner:
     around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -328,6 +328,9 @@ class A2CRunner:
             raise ValueError("collect_launch must be 'graph' or 'eager'")
         self.collect_launch = collect_launch
         self.fused_update = bool(fused_update)
+        # hip_gemms: the update's dense layers through libuavagent's float32 MFMA kernels (csrc/agent_gemm.hip: relu6 masks and bias
+        # gradients fused) instead of torch.mm + separate relu6-backward passes.  They are written for the reference's layer widths.
+        self.hip_gemms = bool(hip_gemms) and HIDDEN == 200 and self.net.n_action <= 640
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
         # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
@@ -342,7 +345,11 @@ class A2CRunner:
         if self.dev.type == "cuda":
             H, NA = HIDDEN, self.net.n_action
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.dev)
-            self._fwd = {"h1a": f(T, N, H), "h1c": f(T, N, H), "h2a": f(T, N, H), "logits": f(T, N, NA)}
+            # logits live in rows of LDL = n_action rounded up to 16 floats (625 -> 640) with a ZERO tail: rows start 16-byte aligned,
+            # so the update's GEMMs stage them with float4 loads and may read the tail (it multiplies zero weights)
+            self._ldl = (NA + 15) // 16 * 16
+            self._logits_pad = torch.zeros((T, N, self._ldl), dtype=torch.float32, device=self.dev)
+            self._fwd = {"h1a": f(T, N, H), "h1c": f(T, N, H), "h2a": f(T, N, H), "logits": self._logits_pad[:, :, :NA]}
         self._fwd_valid = False
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
         # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
@@ -486,21 +493,31 @@ class A2CRunner:
         H, NA, dev = HIDDEN, self.net.n_action, self.dev
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         own = self._fwd is not None and M == self.T * self.env.n_envs      # the rollout's own buffers double as the update's
-        fw = {k: (v.view(M, -1) if own else f(M, v.shape[-1])) for k, v in (self._fwd or {}).items()}
-        if not fw:
-            fw = {"h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H), "logits": f(M, NA)}
-        self._upd = {"M": M, "own": own, "h1a": fw["h1a"], "h1c": fw["h1c"], "h2a": fw["h2a"], "logits": fw["logits"],
-                     "h2c": f(M, H), "dh": f(M, H),
+        ldl = (NA + 15) // 16 * 16
+        if own:
+            fw = {k: self._fwd[k].view(M, H) for k in ("h1a", "h1c", "h2a")}
+            logits_pad = self._logits_pad.view(M, ldl)
+        else:
+            fw = {"h1a": f(M, H), "h1c": f(M, H), "h2a": f(M, H)}
+            logits_pad = torch.zeros((M, ldl), dtype=torch.float32, device=dev)
+        self._upd = {"M": M, "own": own, "h1a": fw["h1a"], "h1c": fw["h1c"], "h2a": fw["h2a"], "logits": logits_pad[:, :NA],
+                     "logits_pad": logits_pad, "h2c": f(M, H), "dh": f(M, H),
                      "gcat": f(M, 2 * H), "v": f(M), "dv": f(M), "target": f(M), "loss": torch.zeros(3, dtype=torch.float64, device=dev),
                      "ws_loss": A.loss_grad_workspace(NA, dev), "ws_relu": A.relu6_bwd_workspace(H, dev),
                      "ws_rows": A.rows_grad_workspace(M, K, 2 * H, self.net.n_state, dev)}
+        if self.hip_gemms:
+            self._upd.update({"w3p": torch.zeros((H, ldl), dtype=torch.float32, device=dev),       # a_w3 in rows of ldl, zero tail
+                              "ws_tn_h": A.gemm_tn_workspace(M, H, dev), "ws_tn_a": A.gemm_tn_workspace(M, NA, dev),
+                              "ws_cs": A.gemm_rows_workspace(M, dev)})
         return self._upd
 
     @torch.no_grad()
     def update_fused(self, idx_buf, act_buf, rew_buf, boot):
-        """The update with a hand-derived backward pass (same mathematics as update_reference, main.py:64-74,143-156):
-        dense layers = torch GEMMs writing straight into the flat gradient buffer; softmax / loss / its gradient, relu6
-        backward + bias gradients, the value head, the table gradient and RMSProp = libuavagent kernels."""
+        """The update with a hand-derived backward pass (same mathematics as update_reference, main.py:64-74,143-156).  Dense layers:
+        libuavagent's float32 MFMA GEMMs (hip_gemms, the default: relu6 backward fused into the dX kernels' epilogue, bias gradients
+        taken from the dW kernels' ones column / the dX kernels' column sums) or torch GEMMs + separate relu6-backward passes;
+        softmax / loss / its gradient, the value head, the table gradient and RMSProp = libuavagent kernels.  Everything writes
+        straight into the flat gradient buffer."""
         from . import _agent_capi as A
 
         net, fl = self.net, self.flat
@@ -510,30 +527,51 @@ class A2CRunner:
         target = A.nstep_returns(rew_buf.contiguous(), boot.contiguous(), self.gamma, out=b["target"].view(T, N)).reshape(M)
         idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
         gv = fl.gv
+        hip = self.hip_gemms
         # forward: the actor's activations and both first layers were computed by the rollout itself, with these very weights
         reuse = b["own"] and self._fwd_valid and idx_buf.data_ptr() == self.idx_buf.data_ptr()
         if not reuse:
             A.sparse_rows_sum(idx, net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=b["h1a"], out_c=b["h1c"])
-            torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
+            if hip:
+                A.gemm_rows(b["h1a"], net.a_w2, b["h2a"], bias=net.a_b2, relu6=True)
+            else:
+                torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
             torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
         self._fwd_valid = False                                        # the backward pass below overwrites logits and h2a
-        torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
+        if hip:
+            A.gemm_rows(b["h1c"], net.c_w2, b["h2c"], bias=net.c_b2, relu6=True)
+        else:
+            torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
         A.rowdot(b["h2c"], net.c_w3, net.c_b3, b["v"])
         # loss and its gradient w.r.t. logits / v (logits are overwritten); d a_b3, d c_b3
         A.a2c_loss_grad(b["logits"], b["v"], target, act, self.beta, b["dv"], gv["a_b3"], b["loss"], b["ws_loss"])
         gv["c_b3"].copy_(b["loss"][2:3].to(torch.float32))
-        # actor trunk backwards
-        torch.mm(b["h2a"].t(), b["logits"], out=gv["a_w3"])
-        torch.mm(b["logits"], net.a_w3.t(), out=b["dh"])
-        A.relu6_bwd(b["dh"], b["h2a"], b["dh"], H, gv["a_b2"], b["ws_relu"])
-        torch.mm(b["h1a"].t(), b["dh"], out=gv["a_w2"])
-        torch.mm(b["dh"], net.a_w2.t(), out=b["h2a"])                 # h2a is free now: reuse it for d h1a
-        A.relu6_bwd(b["h2a"], b["h1a"], b["gcat"], 2 * H, gv["a_b1"], b["ws_relu"])
-        # critic trunk backwards
-        A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
-        torch.mm(b["h1c"].t(), b["dh"], out=gv["c_w2"])
-        torch.mm(b["dh"], net.c_w2.t(), out=b["h2c"])
-        A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
+        if hip:
+            # actor trunk backwards: dW3; dh2a = relu6'(h2a) * (dlogits @ W3^T); dW2 + db2; dh1a = relu6'(h1a) * (dh2a @ W2^T) + db1
+            b["w3p"][:, :net.n_action].copy_(net.a_w3)
+            A.gemm_tn(b["h2a"], b["logits"], gv["a_w3"], b["ws_tn_a"])
+            A.gemm_rows(b["logits_pad"], b["w3p"], b["dh"], w_transposed=True, relu6_mask_h=b["h2a"])
+            A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
+            A.gemm_rows(b["dh"], net.a_w2, b["gcat"][:, :H], w_transposed=True, relu6_mask_h=b["h1a"], colsum_out=gv["a_b1"],
+                        workspace=b["ws_cs"])
+            # critic trunk backwards (the value head's outer product + relu6' + db2 + dw3 stay one streaming kernel)
+            A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
+            A.gemm_tn(b["h1c"], b["dh"], gv["c_w2"], b["ws_tn_h"])
+            A.gemm_rows(b["dh"], net.c_w2, b["gcat"][:, H:], w_transposed=True, relu6_mask_h=b["h1c"], colsum_out=gv["c_b1"],
+                        workspace=b["ws_cs"])
+        else:
+            # actor trunk backwards
+            torch.mm(b["h2a"].t(), b["logits"], out=gv["a_w3"])
+            torch.mm(b["logits"], net.a_w3.t(), out=b["dh"])
+            A.relu6_bwd(b["dh"], b["h2a"], b["dh"], H, gv["a_b2"], b["ws_relu"])
+            torch.mm(b["h1a"].t(), b["dh"], out=gv["a_w2"])
+            torch.mm(b["dh"], net.a_w2.t(), out=b["h2a"])                 # h2a is free now: reuse it for d h1a
+            A.relu6_bwd(b["h2a"], b["h1a"], b["gcat"], 2 * H, gv["a_b1"], b["ws_relu"])
+            # critic trunk backwards
+            A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
+            torch.mm(b["h1c"].t(), b["dh"], out=gv["c_w2"])
+            torch.mm(b["dh"], net.c_w2.t(), out=b["h2c"])
+            A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
         # first-layer tables: both in one sorted pass
         A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
         # synchronise and step
@@ -547,7 +585,7 @@ class A2CRunner:
         loss = b["loss"].cpu()                                        # (synchronises)
         self.stats = {"a_loss": float(loss[0]), "c_loss": float(loss[1]), "mean_reward": float(rew_buf.mean()),
                       "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1),
-                      "forward_reused": bool(reuse)}
+                      "forward_reused": bool(reuse), "hip_gemms": bool(hip)}
         return self.stats
 
     def update_reference(self, idx_buf, act_buf, rew_buf, boot):

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/uavagent.h"
@@ -33,43 +34,120 @@ constexpr int kNP = 208;        // 200 padded to 13 column blocks; 208 = 6 x 32 
                                 // apart, so the two k-rows a 32-lane group of a fragment read touches never share a bank
 constexpr int kRB = 13;         // 16-row blocks of the 200-wide dimension
 
+// Branch-free guarded staging.  LOAD: the address is made safe by a select and the raw value kept in registers (so the load stays in
+// flight behind the MFMAs of the current chunk); STORE: the value is zeroed by a BIT MASK just before it goes to LDS.  (Written as
+// `ok ? *p : 0`, or with a select on the loaded value, hipcc puts every load of the staging pass in a basic block of its own behind an
+// exec branch -- CodeGenPrepare turns a select with a load operand back into a branch; masked right after the load, it waits for
+// every load before the first MFMA.)
+__device__ __forceinline__ float mask_f(float v, bool ok) { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); }
+__device__ __forceinline__ float4 mask_f4(float4 v, bool ok) { return float4{mask_f(v.x, ok), mask_f(v.y, ok), mask_f(v.z, ok), mask_f(v.w, ok)}; }
+__device__ __forceinline__ float4 ldraw4(const float *p, bool ok, const float *safe) { return *reinterpret_cast<const float4 *>(ok ? p : safe); }
+__device__ __forceinline__ float ldraw1(const float *p, bool ok, const float *safe) { return *(ok ? p : safe); }
+
 // =====================================================================================================================
 // dW:  C[i, j] = sum_m A[m, i] * B[m, j]   (A [M, I <= 200], B [M, J]; C [I, J]), plus dbias[j] = sum_m B[m, j].
 //
-// Both operands are streamed once, in 32-row chunks that are contiguous in memory ([32, 200] floats = 25.6 KB), through a double
-// buffered LDS image [k][208].  One workgroup = one (split of M, tile of J) and 4 wavefronts, one per SIMD (the accumulators alone are
-// 172 / 132 VGPRs: this is a 512-register kernel), the 13 x NCB output blocks dealt out so that every SIMD gets the same number of
-// MFMAs: wave w owns all 13 row blocks of NCB / 4 column blocks, and the NCB % 4 left-over column blocks are cut by rows (NCB = 13:
-// 39 + 4 / 3 / 3 / 3 blocks; NCB = 10: 26 + 7 / 6 / 7 / 6).  13 is prime: any rectangular split leaves a SIMD with 49 of 169 blocks
-// (16 % idle).  The accumulators live for the whole split; at the end every workgroup writes ONE slab in fragment order (coalesced
-// 16-byte stores) and gemm_tn_reduce adds the slabs in split order and scatters to C.  A's padding column 200 holds 1.0 in LDS, so row 200 of the product is the column sum of B: the
-// bias gradient of the layer, for free.
+// Both operands are streamed once, in 32-row chunks (a chunk of A is 32 x 200 CONTIGUOUS floats = 25.6 KB), through a double buffered
+// LDS image [k][208] / [k][BJP].  One workgroup = one (split of M, tile of J) and 8 wavefronts, two per SIMD, every one running all 8
+// k-steps of a chunk on its own share of the 13 x NCB output blocks.  The shares are built so that every wavefront issues the same
+// number of MFMAs (13 is prime: any rectangular split of 13 x 13 leaves one wave with 49 of 169 blocks, 16 % idle):
+//   plan 13 (J <= 208, 13 x 13 blocks): waves 0-3 rows 0-6 x 3 columns (21) + block (12, 12) on wave 0; waves 4-7 rows 7-12 x 3 columns
+//            (18) + three blocks of column 12 each (rows 0-11): 22 / 21 MFMAs per k-step;
+//   plan 20 (a 320-wide tile of a wider J, 13 x 20 blocks): wave pair (w, w + 4) shares 5 columns: two whole columns each and column
+//            5 w + 2 cut by rows (0-6 / 7-12): 33 / 32.
+// Fragments for k-step s + 1 are read from LDS while the MFMAs of k-step s issue.  The accumulators (<= 33 blocks = 132 VGPRs) live
+// for the whole split; at the end every workgroup writes ONE slab in fragment order (coalesced 16-byte stores) and gemm_tn_reduce adds
+// the slabs in split order and scatters to C.  A's padding column 200 holds 1.0 in LDS, so row 200 of the product is the column sum of
+// B: the bias gradient of the layer, for free.
 // =====================================================================================================================
-template <int NCB> struct TnPlan {
-    static constexpr int CW = NCB / 4;                  // whole column blocks per wave
-    static constexpr int REM = NCB % 4;                 // left-over column blocks: cut by rows
-    static_assert(REM == 1 || REM == 2, "TnPlan: 13 and 10 column blocks are the tile widths built");
-    static constexpr int NX = (REM == 1) ? 4 : 7;       // most left-over blocks a wave gets
-    static constexpr int NBLK = kRB * CW + NX;          // accumulator blocks per wave (the last ones unused on some waves)
-    static constexpr int BJP = (NCB * 16) % 32 == 16 ? NCB * 16 : NCB * 16 + 16;   // LDS row stride of the B tile: == 16 (mod 32)
-    __host__ __device__ static constexpr int xcol(int wq) { return 4 * CW + (REM == 1 ? 0 : (wq >> 1)); }
-    __host__ __device__ static constexpr int xr0(int wq) { return REM == 1 ? (wq == 0 ? 0 : 1 + 3 * wq) : ((wq & 1) ? 7 : 0); }
-    __host__ __device__ static constexpr int nx(int wq) { return REM == 1 ? (wq == 0 ? 4 : 3) : ((wq & 1) ? 6 : 7); }
+template <int PLAN> struct TnPlan;
+// Every wavefront of a plan has the SAME shape (NR x NC block rectangle + NX single blocks), only the origins differ, so the kernel has
+// one code path (two shapes behind a wave-uniform branch cost hipcc twice the registers: it spilled).  The price: a few duplicate
+// blocks (marked invalid, computed and ignored) on the waves that have fewer real ones.
+template <> struct TnPlan<13> {          // J <= 208: 13 x 13 blocks, 169 real of 8 x 22 issued
+    static constexpr int NCB = 13, BJP = 208, NR = 6, NC = 3, NX = 4, NBLKW = NR * NC + NX;
+    static constexpr bool XONECOL = false;
+    // waves 0-3: rows 0-5 x columns 3 w .. 3 w + 2, extras (6, 3 w + i) and, on wave 0, (12, 12)
+    // waves 4-7: rows 7-12 x the same columns, extras (3 w + i, 12)
+    __host__ __device__ static constexpr int r0(int w) { return (w >> 2) ? 7 : 0; }
+    __host__ __device__ static constexpr int c0(int w) { return 3 * (w & 3); }
+    __host__ __device__ static constexpr int xr(int w, int i) { return (w >> 2) ? 3 * (w & 3) + (i < 3 ? i : 0) : (i < 3 ? 6 : 12); }
+    __host__ __device__ static constexpr int xc(int w, int i) { return (w >> 2) ? 12 : (i < 3 ? 3 * (w & 3) + i : 12); }
+    __host__ __device__ static constexpr bool xvalid(int w, int i) { return i < 3 || w == 0; }
+};
+template <> struct TnPlan<20> {          // a 320-wide tile of a wider J: 13 x 20 blocks, 260 real of 8 x 33 issued
+    static constexpr int NCB = 20, BJP = 336, NR = 13, NC = 2, NX = 7, NBLKW = NR * NC + NX;
+    static constexpr bool XONECOL = true;      // all single blocks of a wave lie in one column: one B fragment serves them
+    // wave pair (w, w + 4) shares columns 5 w .. 5 w + 4: two whole columns each, column 5 w + 2 cut by rows (0-6 / 7-12)
+    __host__ __device__ static constexpr int r0(int) { return 0; }
+    __host__ __device__ static constexpr int c0(int w) { return 5 * (w & 3) + ((w >> 2) ? 3 : 0); }
+    __host__ __device__ static constexpr int xr(int w, int i) { return (w >> 2) ? 7 + (i < 6 ? i : 0) : i; }
+    __host__ __device__ static constexpr int xc(int w, int) { return 5 * (w & 3) + 2; }
+    __host__ __device__ static constexpr bool xvalid(int w, int i) { return (w >> 2) ? i < 6 : true; }
 };
 
 constexpr int kTnBK = 32;       // rows of M per chunk = 8 k-steps of 4
 
-template <int NCB, bool BVEC>
-__global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const float *__restrict__ A, int n_i, const float *__restrict__ B, long long ldb,
+// Diagnostic build (-DUAVGEMM_STAMPS, tools/r03_gemm_stamps.sh): s_memtime at the phase boundaries of gemm_tn_kernel, summed per wavefront
+// into 4 counters behind the slabs (total, prologue, MFMA phases, chunk boundaries).  Values go to that buffer only, never to an output.
+#ifdef UAVGEMM_STAMPS
+#define GEMM_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GEMM_STAMP(var) do { } while (0)
+#endif
+
+// The 8 k-steps of one chunk for one wavefront: an NR x NC block rectangle at (pa, pb) + NX single blocks at (pxa[i], pxb[i]).  The
+// pointers are this lane's element of k row q of the tiles (row strides kNP / BJP); every k-step offset is an immediate of the ds_read.
+// Fragments of k-step s + 1 are read while the MFMAs of k-step s issue, ONE LDS read ahead of each MFMA, in exactly the order written
+// here: a sched_barrier after every MFMA keeps hipcc from (a) bunching the 15-17 reads and their address arithmetic in front of a
+// k-step, where they cost the in-order wave ~40 % more cycles per MFMA (s_memtime stamps, profiles/r03h_*; the partner wave of the SIMD
+// cannot fill such gaps: MI355X_MICROARCH.md, Two waves per SIMD, item 1), and (b) collecting the single-block MFMAs of several k-steps
+// into runs on ONE accumulator (what sched_group_barrier patterns produced: dependent MFMAs back to back, 40 cycles each).
+template <int NR, int NC, int NX, int BJP, bool XONECOL>
+__device__ __forceinline__ void tn_ksteps(const float *pa, const float *pb, const float *const (&pxa)[NX], const float *const (&pxb)[NX],
+                                          f32x4 (&acc)[NR][NC], f32x4 (&accx)[NX]) {
+    float a[2][NR], b[2][NC], xa[2][NX], xb[2][XONECOL ? 1 : NX];
+    constexpr int NXB = XONECOL ? 1 : NX;
+    constexpr int NREADS = NR + NC + NX + NXB, NMFMA = NR * NC + NX;
+    static_assert(NREADS <= NMFMA, "one LDS read per MFMA gap");
+    // read number l of a k-step: A fragments of the rectangle, its B fragments, then the single blocks' A and B fragments
+#define TN_READ(KS, S, L)                                                                                                  \
+    do {                                                                                                                   \
+        if ((L) < NR) a[S][(L) < NR ? (L) : 0] = pa[(KS) * 4 * kNP + (L) * 16];                                           \
+        else if ((L) < NR + NC) b[S][(L) - NR < NC && (L) >= NR ? (L) - NR : 0] = pb[(KS) * 4 * BJP + ((L) - NR) * 16];   \
+        else if ((L) < NR + NC + NX) xa[S][(L) - NR - NC < NX && (L) >= NR + NC ? (L) - NR - NC : 0] = pxa[(L) - NR - NC < NX && (L) >= NR + NC ? (L) - NR - NC : 0][(KS) * 4 * kNP]; \
+        else xb[S][(L) - NR - NC - NX < NXB && (L) >= NR + NC + NX ? (L) - NR - NC - NX : 0] = pxb[(L) - NR - NC - NX < NXB && (L) >= NR + NC + NX ? (L) - NR - NC - NX : 0][(KS) * 4 * BJP]; \
+    } while (0)
+#pragma unroll
+    for (int l = 0; l < NREADS; ++l) TN_READ(0, 0, l);
+#pragma unroll
+    for (int ks = 0; ks < kTnBK / 4; ++ks) {
+        const int cur = ks & 1;
+#pragma unroll
+        for (int m = 0; m < NMFMA; ++m) {
+            if (ks + 1 < kTnBK / 4 && m < NREADS) TN_READ(ks + 1, cur ^ 1, m);
+            if (m < NR * NC) acc[m / NC][m % NC] = MFMA16(a[cur][m / NC], b[cur][m % NC], acc[m / NC][m % NC]);
+            else accx[m - NR * NC] = MFMA16(xa[cur][m - NR * NC], xb[cur][XONECOL ? 0 : m - NR * NC], accx[m - NR * NC]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef TN_READ
+}
+
+template <int PLAN, bool BVEC>
+__global__ __launch_bounds__(512, 1) void gemm_tn_kernel(const float *__restrict__ A, int n_i, const float *__restrict__ B, long long ldb,
                                                           int n_j, long long M, long long rows_per_split, int n_jt, int n_split,
-                                                          f32x4 *__restrict__ slabs) {
-    using P = TnPlan<NCB>;
-    constexpr int CW = P::CW, NX = P::NX, NBLK = P::NBLK, BJP = P::BJP;
+                                                          f32x4 *__restrict__ slabs, int dbg) {
+    using P = TnPlan<PLAN>;
+    constexpr int NCB = P::NCB, BJP = P::BJP, NR = P::NR, NC = P::NC, NX = P::NX, NBLKW = P::NBLKW;
     constexpr int A_TILE = kTnBK * kNP, B_TILE = kTnBK * BJP;
     __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
     float *const sA = lds, *const sB = lds + 2 * A_TILE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches below)
+    unsigned long long ts0 = 0, ts1 = 0, tsa = 0, tsb = 0, tsc = 0, t_mfma = 0, t_bound = 0;
+    (void)ts0; (void)ts1; (void)tsa; (void)tsb; (void)tsc; (void)t_mfma; (void)t_bound;
+    GEMM_STAMP(ts0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches)
     const int r = lane & 15, q = lane >> 4;
     // workgroup -> (split, J tile): the J tiles of one split read the same rows of A, so they sit on one XCD (ids = xcd mod 8) and
     // share its L2 (speed only; any mapping is correct)
@@ -85,138 +163,171 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const float *__restrict
     const int n_chunks = (m1 > m0) ? (int)((m1 - m0 + kTnBK - 1) / kTnBK) : 0;
 
     // ---- LDS image: zero everything once (padding columns must hold finite values), then the column of ones ----
-    for (int i = tid; i < 2 * (A_TILE + B_TILE); i += 256) lds[i] = 0.0f;
+    for (int i = tid; i < 2 * (A_TILE + B_TILE); i += 512) lds[i] = 0.0f;
     __syncthreads();
     if (tid < 2 * kTnBK) sA[(tid >> 5) * A_TILE + (tid & 31) * kNP + n_i] = 1.0f;     // n_i <= 200 (host)
 
-    // ---- per-thread staging plan (the same every chunk).  A: a chunk is 32 x n_i CONTIGUOUS floats, float4 number idx of it goes to
-    // LDS row idx / (n_i / 4).  B: 32 rows of this J tile, float4s (BVEC) or floats. ----
-    constexpr int NAL = 7;                                               // 32 x 200 / 4 = 1600 float4 over 256 threads
+    // ---- per-thread staging plan (the same every chunk).  A: float4 number idx of the contiguous chunk goes to LDS row idx / (n_i / 4).
+    // B: 32 rows of this J tile, float4s (BVEC: the row stride and the tile origin are multiples of 4 floats and the columns up to the
+    // next multiple of 4 past n_j are readable and finite -- they only feed output columns >= n_j, which are never stored) or floats. ----
+    constexpr int NAL = 4;                                               // 32 x 200 / 4 = 1600 float4 over 512 threads
     const int a4 = n_i >> 2;
     int a_lds[NAL];
 #pragma unroll
-    for (int i = 0; i < NAL; ++i) { const int idx = tid + 256 * i, row = idx / a4; a_lds[i] = row * kNP + (idx - row * a4) * 4; }
-    const int bj = (n_j - j0 < NCB * 16) ? n_j - j0 : NCB * 16;          // valid columns of this J tile
-    constexpr int NBL = BVEC ? 7 : (kTnBK * NCB * 16 + 255) / 256;        // staging loads per thread for B
-    const int b4 = BVEC ? (bj >> 2) : NCB * 16;                          // items per row (float4s / floats)
-    int b_row[BVEC ? NBL : 1], b_c[BVEC ? NBL : 1];
+    for (int i = 0; i < NAL; ++i) { const int idx = tid + 512 * i, row = idx / a4; a_lds[i] = row * kNP + (idx - row * a4) * 4; }
+    const int n_j4 = (n_j + 3) & ~3;
+    const int bj = BVEC ? ((n_j4 - j0 < NCB * 16) ? n_j4 - j0 : NCB * 16) : ((n_j - j0 < NCB * 16) ? n_j - j0 : NCB * 16);   // columns staged
+    constexpr int NBL = BVEC ? (kTnBK * NCB * 4 + 511) / 512 : (kTnBK * NCB * 16 + 511) / 512;
+    int b_lds[BVEC ? NBL : 1], b_g[BVEC ? NBL : 1];     // (row < rows  <=>  b_g < rows * ldb;  row < 32  <=>  b_lds < 32 * BJP)
     if (BVEC) {
+        const int b4 = bj >> 2;
 #pragma unroll
-        for (int i = 0; i < NBL; ++i) { const int idx = tid + 256 * i; b_row[BVEC ? i : 0] = idx / b4; b_c[BVEC ? i : 0] = idx - (idx / b4) * b4; }
+        for (int i = 0; i < NBL; ++i) {
+            const int idx = tid + 512 * i, row = idx / b4, c4 = idx - row * b4;
+            b_lds[BVEC ? i : 0] = row * BJP + c4 * 4; b_g[BVEC ? i : 0] = row * (int)ldb + c4 * 4;
+        }
     }
 
     float4 ra[NAL];
     float4 rbv[BVEC ? NBL : 1];
     float rbs[BVEC ? 1 : NBL];
-    auto load_chunk = [&](int c) {
+    auto chunk_rows = [&](int c) { const long long mb = m0 + (long long)c * kTnBK; return (m1 - mb < kTnBK) ? (int)(m1 - mb) : kTnBK; };   // >= 1
+    auto load_chunk = [&](int c) {                       // raw loads from safe addresses; store_chunk zeroes what does not exist
         const long long mb = m0 + (long long)c * kTnBK;
-        const int rows = (m1 - mb < kTnBK) ? (int)(m1 - mb) : kTnBK;     // rows of this chunk that exist
+        const int rows = chunk_rows(c);
         const float *ga = A + mb * (long long)n_i;
+        const float *gb = B + mb * ldb + j0;
 #pragma unroll
-        for (int i = 0; i < NAL; ++i) {
-            const int idx = tid + 256 * i;
-            ra[i] = (idx < rows * a4) ? *reinterpret_cast<const float4 *>(ga + idx * 4) : float4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < NAL; ++i) { const int idx = tid + 512 * i; ra[i] = ldraw4(ga + idx * 4, idx < rows * a4, ga); }
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
-            if (BVEC) {
-                const int br = b_row[BVEC ? i : 0];
-                rbv[BVEC ? i : 0] = (br < rows) ? *reinterpret_cast<const float4 *>(B + (mb + br) * ldb + j0 + b_c[BVEC ? i : 0] * 4) : float4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                const int idx = tid + 256 * i, br = idx / (NCB * 16), bc = idx - br * (NCB * 16);
-                rbs[BVEC ? 0 : i] = (br < rows && bc < bj) ? B[(mb + br) * ldb + j0 + bc] : 0.0f;
+            if (BVEC) rbv[BVEC ? i : 0] = ldraw4(gb + b_g[BVEC ? i : 0], b_g[BVEC ? i : 0] < rows * (int)ldb, gb);
+            else {
+                const int idx = tid + 512 * i, br = idx / (NCB * 16), bc = idx - br * (NCB * 16);
+                rbs[BVEC ? 0 : i] = ldraw1(gb + (long long)br * ldb + bc, br < rows && bc < bj, gb);
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int c) {
+        const int rows = chunk_rows(c);
         float *dA = sA + buf * A_TILE, *dB = sB + buf * B_TILE;
 #pragma unroll
-        for (int i = 0; i < NAL; ++i)
-            if (tid + 256 * i < kTnBK * a4) *reinterpret_cast<float4 *>(dA + a_lds[i]) = ra[i];
+        for (int i = 0; i < NAL; ++i) {
+            const int idx = tid + 512 * i;
+            if (idx < kTnBK * a4) *reinterpret_cast<float4 *>(dA + a_lds[i]) = mask_f4(ra[i], idx < rows * a4);
+        }
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             if (BVEC) {
-                if (b_row[BVEC ? i : 0] < kTnBK) *reinterpret_cast<float4 *>(dB + b_row[BVEC ? i : 0] * BJP + b_c[BVEC ? i : 0] * 4) = rbv[BVEC ? i : 0];
+                if (b_lds[BVEC ? i : 0] < kTnBK * BJP) *reinterpret_cast<float4 *>(dB + b_lds[BVEC ? i : 0]) = mask_f4(rbv[BVEC ? i : 0], b_g[BVEC ? i : 0] < rows * (int)ldb);
             } else {
-                const int idx = tid + 256 * i, br = idx / (NCB * 16), bc = idx - br * (NCB * 16);
-                if (br < kTnBK) dB[br * BJP + bc] = rbs[BVEC ? 0 : i];
+                const int idx = tid + 512 * i, br = idx / (NCB * 16), bc = idx - br * (NCB * 16);
+                if (br < kTnBK) dB[br * BJP + bc] = mask_f(rbs[BVEC ? 0 : i], br < rows && bc < bj);
             }
         }
     };
 
-    f32x4 acc[kRB][CW], accx[NX];
+    f32x4 acc[NR][NC], accx[NX];
 #pragma unroll
-    for (int i = 0; i < kRB; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
-        for (int c = 0; c < CW; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NC; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NX; ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int xcol = P::xcol(wq), xr0 = P::xr0(wq), nx = P::nx(wq);
+    const int fa = q * kNP + r, fb = q * BJP + r;                      // this lane's element of k row q
+    const int oa = fa + P::r0(wave) * 16, ob = fb + P::c0(wave) * 16;
+    int oxa[NX], oxb[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { oxa[i] = fa + P::xr(wave, i) * 16; oxb[i] = fb + P::xc(wave, i) * 16; }
+    const float *pxa[NX], *pxb[NX];
 
-    if (n_chunks > 0) { load_chunk(0); store_chunk(0); }
+    if (n_chunks > 0) { load_chunk(0); store_chunk(0, 0); }
     __syncthreads();
+    GEMM_STAMP(ts1);
+    tsc = ts1;
+#ifdef UAVGEMM_STAMPS
+    if ((dbg & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((dbg & 8) && wave < 4) __builtin_amdgcn_s_setprio(1);
+    const bool skip = ((dbg & 2) && wave >= 4) || ((dbg & 4) && wave < 4);
+#else
+    (void)dbg;
+    constexpr bool skip = false;
+#endif
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
+        tsa = tsc;
         if (c + 1 < n_chunks) load_chunk(c + 1);                           // in flight behind this chunk's MFMAs
-        const float *tA = sA + buf * A_TILE + q * kNP + r, *tB = sB + buf * B_TILE + q * BJP + r;
+        const float *tA = sA + buf * A_TILE, *tB = sB + buf * B_TILE;
 #pragma unroll
-        for (int ks = 0; ks < kTnBK / 4; ++ks) {
-            const float *pa = tA + ks * 4 * kNP, *pb = tB + ks * 4 * BJP;    // this lane's k row of the k-step
-            float a[kRB], b[CW];
-#pragma unroll
-            for (int i = 0; i < kRB; ++i) a[i] = pa[i * 16];
-#pragma unroll
-            for (int cc = 0; cc < CW; ++cc) b[cc] = pb[(wq * CW + cc) * 16];
-            const float bx = pb[xcol * 16];
-            float ax[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) ax[i] = pa[((i < nx) ? xr0 + i : 0) * 16];
-#pragma unroll
-            for (int i = 0; i < kRB; ++i)
-#pragma unroll
-                for (int cc = 0; cc < CW; ++cc) acc[i][cc] = MFMA16(a[i], b[cc], acc[i][cc]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-                if (i < nx) accx[i] = MFMA16(ax[i], bx, accx[i]);            // (wave-uniform branch)
-        }
-        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+        for (int i = 0; i < NX; ++i) { pxa[i] = tA + oxa[i]; pxb[i] = tB + oxb[i]; }
+        if (!skip) tn_ksteps<NR, NC, NX, BJP, P::XONECOL>(tA + oa, tB + ob, pxa, pxb, acc, accx);
+        GEMM_STAMP(tsb);
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1, c + 1);
         __syncthreads();
+        GEMM_STAMP(tsc);
+        t_mfma += tsb - tsa; t_bound += tsc - tsb;
     }
 
-    // ---- one slab per workgroup, in fragment order (coalesced 16-byte stores) ----
-    f32x4 *dst = slabs + (((long long)split * n_jt + jt) * 4 + wq) * (long long)(NBLK * 64) + lane;
+    // ---- one slab per workgroup, in fragment order (coalesced 16-byte stores): [wave][block][lane], blocks of a wave = its rectangle
+    // row by row, then its single blocks ----
+    f32x4 *dst = slabs + (((long long)split * n_jt + jt) * 8 + wave) * (long long)(NBLKW * 64) + lane;
 #pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) dst[blk * 64] = (blk < kRB * CW) ? acc[blk / CW][blk % CW] : accx[blk - kRB * CW];
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dst[(i * NC + c) * 64] = acc[i][c];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dst[(NR * NC + i) * 64] = accx[i];
+#ifdef UAVGEMM_STAMPS
+    unsigned long long ts2;
+    GEMM_STAMP(ts2);
+    if (lane == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(slabs + (long long)n_split * n_jt * 8 * NBLKW * 64) + ((long long)blockIdx.x * 8 + wave) * 4;
+        d[0] = ts2 - ts0; d[1] = ts1 - ts0; d[2] = t_mfma; d[3] = t_bound;
+    }
+#endif
 }
 
-// Second pass of dW: one thread per accumulator fragment (jt, wave, block, lane) adds the slabs in split order (fixed order: the
-// result does not depend on scheduling) and scatters its 4 values; row n_i of the product (the ones column) goes to dbias.
-template <int NCB>
+// Second pass of dW: 64 accumulator fragments (J tile, wave, block, lane) per workgroup, each summed over the splits by four threads (a
+// quarter of the splits each, ascending) whose partial sums are then added in quarter order: a fixed association, so the result does
+// not depend on scheduling.  Row n_i of the product (the ones column) goes to dbias.
+template <int PLAN>
 __global__ __launch_bounds__(256) void gemm_tn_reduce(const f32x4 *__restrict__ slabs, int n_split, int n_jt, int n_i, int n_j, float *__restrict__ C,
                                                        long long ldc, float *__restrict__ dbias) {
-    using P = TnPlan<NCB>;
-    constexpr int CW = P::CW, NBLK = P::NBLK;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int per_slab = 4 * NBLK * 64;
-    if (t >= n_jt * per_slab) return;
-    const int jt = t / per_slab, rem = t - jt * per_slab;
-    const int wq = rem / (NBLK * 64), rem2 = rem - wq * (NBLK * 64), blk = rem2 >> 6, lane = rem2 & 63;
+    using P = TnPlan<PLAN>;
+    constexpr int NBLKW = P::NBLKW, NC = P::NC, NMAIN = P::NR * P::NC;
+    __shared__ f32x4 part[4][64];
+    const int it = threadIdx.x & 63, sq = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + it;
+    const int per_slab = 8 * NBLKW * 64;
+    const bool live = t < n_jt * per_slab;
+    const int tt = live ? t : 0;
+    const int jt = tt / per_slab, rem = tt - jt * per_slab;
+    const int wave = rem / (NBLKW * 64), rem2 = rem - wave * (NBLKW * 64), blk = rem2 >> 6, lane = rem2 & 63;
     const f32x4 *src = slabs + (long long)jt * per_slab + rem;
     const long long stride = (long long)n_jt * per_slab;
+    const int per_q = (n_split + 3) / 4;
+    int s = sq * per_q;
+    const int s1 = (s + per_q < n_split) ? s + per_q : n_split;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= n_split; s += 8) {
-        f32x4 w[8];
+    if (live) {
+        for (; s + 8 <= s1; s += 8) {
+            f32x4 w[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = src[(s + i) * stride];
+            for (int i = 0; i < 8; ++i) w[i] = src[(s + i) * stride];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v += w[i];
+            for (int i = 0; i < 8; ++i) v += w[i];
+        }
+        for (; s < s1; ++s) v += src[s * stride];
     }
-    for (; s < n_split; ++s) v += src[s * stride];
+    part[sq][it] = v;
+    __syncthreads();
+    if (sq != 0 || !live) return;
     int rb, cb;
-    if (blk < kRB * CW) { rb = blk / CW; cb = wq * CW + blk % CW; }
-    else { const int i = blk - kRB * CW; if (i >= P::nx(wq)) return; rb = P::xr0(wq) + i; cb = P::xcol(wq); }
-    const int col = jt * NCB * 16 + cb * 16 + (lane & 15);
+    if (blk < NMAIN) { rb = P::r0(wave) + blk / NC; cb = P::c0(wave) + blk % NC; }
+    else { const int i = blk - NMAIN; if (!P::xvalid(wave, i)) return; rb = P::xr(wave, i); cb = P::xc(wave, i); }
+    v = part[0][it];
+    v += part[1][it]; v += part[2][it]; v += part[3][it];
+    const int col = jt * P::NCB * 16 + cb * 16 + (lane & 15);
     if (col >= n_j) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -235,17 +346,22 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const f32x4 *__restrict__ 
 // One workgroup = 128 rows x all N columns, 4 wavefronts of 32 rows x 13 column blocks (104 accumulator VGPRs), two workgroups per
 // CU so that one computes while the other loads or stores.  K is walked in chunks of 20 (5 k-steps) through double-buffered LDS:
 // the A tile as [row][22] (stride 22: the 16 rows x 2 k of a fragment read fall on 32 different banks), the W tile as [k][208] (NT
-// false) or [n][22] (NT true).  VEC = false loads dword by dword (row strides that are not a multiple of 4 floats: the 625-wide
-// policy head).
+// false) or [n][22] (NT true).  The fast kernel (gemm_rows_vec_kernel) needs 16-byte aligned operands and row strides / K / N that are
+// multiples of 4 floats: float4 staging loads without branches, fragments of k-step s + 1 read while k-step s issues, and an epilogue
+// that goes through LDS so that C (and H) move as whole 16-byte pieces of contiguous rows instead of 64-byte column fragments.
+// gemm_rows_kernel<.., VEC = false> is the general form (dword loads, direct epilogue) for everything else.
 // =====================================================================================================================
 constexpr int kRowsBM = 128, kRowsBK = 20, kRowsLD = 22;
 constexpr int kRowsATile = kRowsBM * kRowsLD;                                   // 2816 floats
 constexpr int kRowsWTile = (kRowsBK * kNP > kNP * kRowsLD) ? kRowsBK * kNP : kNP * kRowsLD;   // 4576 floats
+constexpr int kRowsLDC = 212;                                                   // epilogue staging row stride (848 B = 53 x 16)
+static_assert(4 * 16 * kRowsLDC <= 2 * (kRowsATile + kRowsWTile), "epilogue staging must fit the tile buffers");
 
-template <bool NT, bool VEC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
-                                                            int K, int N, long long M, const float *__restrict__ bias, int relu6,
-                                                            const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc) {
+template <bool NT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+                                                                int K, int N, long long M, const float *__restrict__ bias, int relu6,
+                                                                const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc,
+                                                                float *__restrict__ col_partial) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (kRowsATile + kRowsWTile)];
     float *const sA = lds, *const sW = lds + 2 * kRowsATile;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,77 +371,57 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restri
     for (int i = tid; i < 2 * (kRowsATile + kRowsWTile); i += 256) lds[i] = 0.0f;   // padding rows / columns must be finite
     __syncthreads();
 
-    // staging plan.  VEC: A = 128 rows x 5 float4 (3 loads per thread), W = 1000 float4 (4 loads); else 10 + 16 dword loads.
-    constexpr int NA = VEC ? 3 : 10, NW = VEC ? 4 : 17;
-    constexpr int APR = VEC ? kRowsBK / 4 : kRowsBK;            // items per A row
-    int a_row[NA], a_c[NA];
+    // staging plan: A = 128 rows x 5 float4 (3 loads per thread), W = 1000 float4 at N = 200 (<= 1040: 5 loads cover N <= 208)
+    constexpr int NA = 3, NW = 5;
+    int a_g[NA], a_l[NA], a_k[NA];
+    bool a_ok[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { const int idx = tid + 256 * i; a_row[i] = idx / APR; a_c[i] = idx - a_row[i] * APR; }
-    // W items: NT false: [k (20)][N / 4 or N];  NT true: [n (N)][5 or 20]
-    const int wpr = NT ? APR : (VEC ? (N >> 2) : N);            // items per W-tile row
-    const int w_rows = NT ? N : kRowsBK;
-    int w_row[NW], w_c[NW];
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + 256 * i, row = idx / 5, c4 = idx - row * 5;
+        a_g[i] = row * (int)lda + c4 * 4; a_l[i] = row * kRowsLD + c4 * 4; a_k[i] = c4 * 4;
+        a_ok[i] = (row < kRowsBM) && (m0 + row < M);
+    }
+    const int n4 = N >> 2;
+    int w_g[NW], w_l[NW], w_k[NW];
+    bool w_ok[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { const int idx = tid + 256 * i; w_row[i] = idx / wpr; w_c[i] = idx - w_row[i] * wpr; }
-
-    float4 va[VEC ? NA : 1], vw[VEC ? NW : 1];
-    float fa[VEC ? 1 : NA], fw[VEC ? 1 : NW];
-    auto load_chunk = [&](int c) {
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + 256 * i;
+        if (NT) {     // W [N, K]: tile row = n, 5 float4 of k per row
+            const int row = idx / 5, c4 = idx - row * 5;
+            w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = row * kRowsLD + c4 * 4; w_k[i] = c4 * 4; w_ok[i] = row < N;
+        } else {      // W [K, N]: tile row = k (20), N / 4 float4 per row
+            const int row = idx / n4, c4 = idx - row * n4;
+            w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = row * kNP + c4 * 4; w_k[i] = row; w_ok[i] = row < kRowsBK;
+        }
+    }
+    float4 va[NA], vw[NW];
+    const float *gA = A + m0 * lda;
+    auto load_chunk = [&](int c) {                       // raw loads from safe addresses; store_chunk zeroes what does not exist
         const int k0 = c * kRowsBK;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const long long m = m0 + a_row[i];
-            if (VEC) {
-                const bool ok = (a_row[i] < kRowsBM) && (m < M) && (k0 + a_c[i] * 4 < K);    // K % 4 == 0 on this path
-                va[VEC ? i : 0] = ok ? *reinterpret_cast<const float4 *>(A + m * lda + k0 + a_c[i] * 4) : float4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                const bool ok = (a_row[i] < kRowsBM) && (m < M) && (k0 + a_c[i] < K);
-                fa[VEC ? 0 : i] = ok ? A[m * lda + k0 + a_c[i]] : 0.0f;
-            }
-        }
+        for (int i = 0; i < NA; ++i) va[i] = ldraw4(gA + k0 + a_g[i], a_ok[i] && (k0 + a_k[i] < K), A);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            if (NT) {      // W [N, K]: row = n, column = k0 + ...
-                if (VEC) {
-                    const bool ok = (w_row[i] < w_rows) && (k0 + w_c[i] * 4 < K);
-                    vw[VEC ? i : 0] = ok ? *reinterpret_cast<const float4 *>(W + (long long)w_row[i] * ldw + k0 + w_c[i] * 4) : float4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    const bool ok = (w_row[i] < w_rows) && (k0 + w_c[i] < K);
-                    fw[VEC ? 0 : i] = ok ? W[(long long)w_row[i] * ldw + k0 + w_c[i]] : 0.0f;
-                }
-            } else {       // W [K, N]: row = k0 + ..., column = n
-                if (VEC) {
-                    const bool ok = (w_row[i] < w_rows) && (k0 + w_row[i] < K);
-                    vw[VEC ? i : 0] = ok ? *reinterpret_cast<const float4 *>(W + (long long)(k0 + w_row[i]) * ldw + w_c[i] * 4) : float4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    const bool ok = (w_row[i] < w_rows) && (k0 + w_row[i] < K);
-                    fw[VEC ? 0 : i] = ok ? W[(long long)(k0 + w_row[i]) * ldw + w_c[i]] : 0.0f;
-                }
-            }
-        }
+        for (int i = 0; i < NW; ++i) vw[i] = ldraw4(W + (NT ? (long long)k0 : (long long)k0 * ldw) + w_g[i], w_ok[i] && (k0 + w_k[i] < K), W);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int c) {
+        const int k0 = c * kRowsBK;
         float *dA = sA + buf * kRowsATile, *dW = sW + buf * kRowsWTile;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            if (a_row[i] < kRowsBM) {
-                if (VEC) {      // row stride 22 floats = 88 B: 8-byte aligned, two 8-byte stores
-                    float2 *d = reinterpret_cast<float2 *>(dA + a_row[i] * kRowsLD + a_c[i] * 4);
-                    d[0] = float2{va[VEC ? i : 0].x, va[VEC ? i : 0].y}; d[1] = float2{va[VEC ? i : 0].z, va[VEC ? i : 0].w};
-                } else dA[a_row[i] * kRowsLD + a_c[i]] = fa[VEC ? 0 : i];
+            if (tid + 256 * i < kRowsBM * 5) {      // row stride 22 floats = 88 B: 8-byte aligned, two 8-byte stores
+                const float4 v = mask_f4(va[i], a_ok[i] && (k0 + a_k[i] < K));
+                float2 *d = reinterpret_cast<float2 *>(dA + a_l[i]);
+                d[0] = float2{v.x, v.y}; d[1] = float2{v.z, v.w};
             }
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            if (w_row[i] < w_rows) {
+            if (w_ok[i]) {
+                const float4 v = mask_f4(vw[i], k0 + w_k[i] < K);
                 if (NT) {
-                    if (VEC) {
-                        float2 *d = reinterpret_cast<float2 *>(dW + w_row[i] * kRowsLD + w_c[i] * 4);
-                        d[0] = float2{vw[VEC ? i : 0].x, vw[VEC ? i : 0].y}; d[1] = float2{vw[VEC ? i : 0].z, vw[VEC ? i : 0].w};
-                    } else dW[w_row[i] * kRowsLD + w_c[i]] = fw[VEC ? 0 : i];
-                } else {
-                    if (VEC) *reinterpret_cast<float4 *>(dW + w_row[i] * kNP + w_c[i] * 4) = vw[VEC ? i : 0];
-                    else dW[w_row[i] * kNP + w_c[i]] = fw[VEC ? 0 : i];
-                }
+                    float2 *d = reinterpret_cast<float2 *>(dW + w_l[i]);
+                    d[0] = float2{v.x, v.y}; d[1] = float2{v.z, v.w};
+                } else *reinterpret_cast<float4 *>(dW + w_l[i]) = v;
             }
     };
 
@@ -337,27 +433,188 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restri
 
     const int n_chunks = (K + kRowsBK - 1) / kRowsBK;
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    const int fa = (wave * 32 + r) * kRowsLD + q, fw = NT ? (r * kRowsLD + q) : (q * kNP + r);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) load_chunk(c + 1);
+        const float *tA = sA + buf * kRowsATile + fa, *tW = sW + buf * kRowsWTile + fw;
+        // all 5 k-steps, always: k >= K was staged as zeros in BOTH tiles.  Fragments of k-step s + 1 are read while k-step s issues, one
+        // LDS read ahead of each MFMA, in source order (sched_barrier after every MFMA: see tn_ksteps).
+        float a[2][2], b[2][kRB];
+#define ROWS_READ(KS, S, L)                                                                                                  \
+        do {                                                                                                                \
+            if ((L) < 2) a[S][(L) < 2 ? (L) : 0] = tA[(L) * 16 * kRowsLD + (KS) * 4];                                       \
+            else b[S][(L) >= 2 ? (L) - 2 : 0] = NT ? tW[((L) - 2) * 16 * kRowsLD + (KS) * 4] : tW[(KS) * 4 * kNP + ((L) - 2) * 16]; \
+        } while (0)
+#pragma unroll
+        for (int l = 0; l < kRB + 2; ++l) ROWS_READ(0, 0, l);
+#pragma unroll
+        for (int ks = 0; ks < kRowsBK / 4; ++ks) {
+            const int cur = ks & 1;
+#pragma unroll
+            for (int m = 0; m < 2 * kRB; ++m) {
+                if (ks + 1 < kRowsBK / 4 && m < kRB + 2) ROWS_READ(ks + 1, cur ^ 1, m);
+                acc[m & 1][m >> 1] = MFMA16(a[cur][m & 1], b[cur][m >> 1], acc[m & 1][m >> 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef ROWS_READ
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1, c + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: wave w stages 16 rows x 208 columns at a time (accumulator register t of block cb = row 4 q + t, column
+    // cb * 16 + r), then lane l < N / 4 moves float4 number l of one whole row per instruction: 800 contiguous bytes per wave-instruction
+    // for C (and for H) instead of dword accesses that touch 64 bytes per row.  Each lane thereby owns 4 fixed columns, so the column
+    // sums of what is stored (the bias gradient of the layer below, col_partial != nullptr) are a running float4 per lane: rows ascending
+    // inside the wave, then the 4 waves in order, then the workgroups in order (rows_colsum_reduce): bit-reproducible. ----
+    float *E = lds + wave * (16 * kRowsLDC);
+    float4 cs = float4{0.f, 0.f, 0.f, 0.f};
+    const bool col_ok = lane < n4;
+    float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1 && bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(bias + lane * 4);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < kRB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) E[(4 * q + t) * kRowsLDC + cb * 16 + r] = acc[rb][cb][t];
+        __syncthreads();                       // (a wave reads only what it wrote itself; the barrier orders its lanes' writes and reads)
+#pragma unroll 4
+        for (int row = 0; row < 16; ++row) {
+            const long long m = m0 + wave * 32 + rb * 16 + row;
+            if (col_ok && m < M) {
+                float4 v = *reinterpret_cast<const float4 *>(E + row * kRowsLDC + lane * 4);
+                if (EPI == 1) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (relu6) { v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f); }
+                }
+                if (EPI == 2) {
+                    const float4 h = *reinterpret_cast<const float4 *>(H + m * ldh + lane * 4);
+                    v.x = (h.x > 0.f && h.x < 6.f) ? v.x : 0.f; v.y = (h.y > 0.f && h.y < 6.f) ? v.y : 0.f;
+                    v.z = (h.z > 0.f && h.z < 6.f) ? v.z : 0.f; v.w = (h.w > 0.f && h.w < 6.f) ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(C + m * ldc + lane * 4) = v;
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (col_partial != nullptr) {
+        float4 *S = reinterpret_cast<float4 *>(lds);                       // [4 waves][52 float4]
+        if (lane < 52) S[wave * 52 + lane] = cs;
+        __syncthreads();
+        if (wave == 0 && lane < 52) {
+            float4 t = S[lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const float4 u = S[w * 52 + lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            *reinterpret_cast<float4 *>(col_partial + (long long)blockIdx.x * kNP + lane * 4) = t;
+        }
+    }
+}
+
+// out[c] = sum over workgroups of col_partial[wg][c], in a fixed order: a block owns 64 columns, 16 slab-threads per column each add a
+// contiguous slab of the partial rows in ascending order, then the 16 slab sums are added in slab order.
+__global__ __launch_bounds__(1024) void rows_colsum_reduce(const float *__restrict__ partial, long long n_part, int n_cols, float *__restrict__ out) {
+    __shared__ float slab_sum[16][64];
+    const int cl = threadIdx.x & 63, slab = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long per = (n_part + 15) / 16;
+    const long long w0 = slab * per, w1 = (w0 + per < n_part) ? w0 + per : n_part;
+    float sum = 0.f;
+    if (c < n_cols) {
+        long long w = w0;
+        for (; w + 4 <= w1; w += 4) {
+            const float a0 = partial[w * kNP + c], a1 = partial[(w + 1) * kNP + c], a2 = partial[(w + 2) * kNP + c], a3 = partial[(w + 3) * kNP + c];
+            sum += a0; sum += a1; sum += a2; sum += a3;
+        }
+        for (; w < w1; ++w) sum += partial[w * kNP + c];
+    }
+    slab_sum[slab][cl] = sum;
+    __syncthreads();
+    if (slab == 0 && c < n_cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += slab_sum[k][cl];
+        out[c] = t;
+    }
+}
+
+template <bool NT, bool VEC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+                                                            int K, int N, long long M, const float *__restrict__ bias, int relu6,
+                                                            const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc) {
+    static_assert(!VEC, "the aligned shapes run gemm_rows_vec_kernel");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (kRowsATile + kRowsWTile)];
+    float *const sA = lds, *const sW = lds + 2 * kRowsATile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * kRowsBM;
+
+    for (int i = tid; i < 2 * (kRowsATile + kRowsWTile); i += 256) lds[i] = 0.0f;   // padding rows / columns must be finite
+    __syncthreads();
+
+    constexpr int NA = 10, NW = 17;                              // 128 x 20 and <= 208 x 20 floats over 256 threads
+    const int wpr = NT ? kRowsBK : N;                            // items per W-tile row
+    const int w_rows = NT ? N : kRowsBK;
+    float fa[NA], fw[NW];
+    auto load_chunk = [&](int c) {
+        const int k0 = c * kRowsBK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i, row = idx / kRowsBK, kk = idx - row * kRowsBK;
+            const long long m = m0 + row;
+            fa[i] = ldraw1(A + m * lda + k0 + kk, (row < kRowsBM) && (m < M) && (k0 + kk < K), A);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + 256 * i, row = idx / wpr, cc = idx - row * wpr;
+            if (NT) fw[i] = ldraw1(W + (long long)row * ldw + k0 + cc, (row < w_rows) && (k0 + cc < K), W);       // W [N, K]
+            else fw[i] = ldraw1(W + (long long)(k0 + row) * ldw + cc, (row < w_rows) && (k0 + row < K), W);       // W [K, N]
+        }
+    };
+    auto store_chunk = [&](int buf, int c) {
+        const int k0 = c * kRowsBK;
+        float *dA = sA + buf * kRowsATile, *dW = sW + buf * kRowsWTile;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i, row = idx / kRowsBK, kk = idx - row * kRowsBK;
+            if (row < kRowsBM) dA[row * kRowsLD + kk] = mask_f(fa[i], (m0 + row < M) && (k0 + kk < K));
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + 256 * i, row = idx / wpr, cc = idx - row * wpr;
+            if (row < w_rows) dW[row * (NT ? kRowsLD : kNP) + cc] = mask_f(fw[i], NT ? (k0 + cc < K) : (k0 + row < K));
+        }
+    };
+
+    f32x4 acc[2][kRB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < kRB; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunks = (K + kRowsBK - 1) / kRowsBK;
+    load_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) load_chunk(c + 1);
         const float *tA = sA + buf * kRowsATile + (wave * 32 + r) * kRowsLD + q;
         const float *tW = NT ? (sW + buf * kRowsWTile + r * kRowsLD + q) : (sW + buf * kRowsWTile + q * kNP + r);
-        const int kleft = K - c * kRowsBK;
-        const int nks = (kleft >= kRowsBK) ? kRowsBK / 4 : (kleft + 3) / 4;
 #pragma unroll
-        for (int ks = 0; ks < kRowsBK / 4; ++ks) {
-            if (ks < nks) {
-                const float a0 = tA[ks * 4], a1 = tA[16 * kRowsLD + ks * 4];
-                float b[kRB];
+        for (int ks = 0; ks < kRowsBK / 4; ++ks) {               // k >= K was staged as zeros in both tiles
+            const float a0 = tA[ks * 4], a1 = tA[16 * kRowsLD + ks * 4];
+            float b[kRB];
 #pragma unroll
-                for (int cb = 0; cb < kRB; ++cb) b[cb] = NT ? tW[cb * 16 * kRowsLD + ks * 4] : tW[ks * 4 * kNP + cb * 16];
+            for (int cb = 0; cb < kRB; ++cb) b[cb] = NT ? tW[cb * 16 * kRowsLD + ks * 4] : tW[ks * 4 * kNP + cb * 16];
 #pragma unroll
-                for (int cb = 0; cb < kRB; ++cb) { acc[0][cb] = MFMA16(a0, b[cb], acc[0][cb]); acc[1][cb] = MFMA16(a1, b[cb], acc[1][cb]); }
-            }
+            for (int cb = 0; cb < kRB; ++cb) { acc[0][cb] = MFMA16(a0, b[cb], acc[0][cb]); acc[1][cb] = MFMA16(a1, b[cb], acc[1][cb]); }
         }
-        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1, c + 1);
         __syncthreads();
     }
 
@@ -391,12 +648,12 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct TnShape { int ncb, n_jt, n_split; long long rows_per_split; size_t ws_bytes; };
+struct TnShape { int plan, n_jt, n_split; long long rows_per_split; size_t ws_bytes; };
 // The split of M: one workgroup per CU (256 on MI355X) in total; every split a whole number of 32-row chunks.
 TnShape tn_shape(long long M, int n_j) {
     TnShape s;
-    s.ncb = (n_j <= 208) ? 13 : 10;
-    s.n_jt = (n_j <= 208) ? 1 : (n_j + 159) / 160;
+    s.plan = (n_j <= 208) ? 13 : 20;
+    s.n_jt = (n_j <= 208) ? 1 : (n_j + 319) / 320;
     int want = 256 / s.n_jt;
     if (want < 8) want = 8;
     const long long chunks = (M + kTnBK - 1) / kTnBK;
@@ -405,8 +662,11 @@ TnShape tn_shape(long long M, int n_j) {
     s.rows_per_split = per * kTnBK;
     s.n_split = (int)((M + s.rows_per_split - 1) / s.rows_per_split);
     if (s.n_split < 1) s.n_split = 1;
-    const int nblk = (s.ncb == 13) ? TnPlan<13>::NBLK : TnPlan<10>::NBLK;
-    s.ws_bytes = (size_t)s.n_split * s.n_jt * 4 * nblk * 64 * sizeof(f32x4);
+    const int nblkw = (s.plan == 13) ? TnPlan<13>::NBLKW : TnPlan<20>::NBLKW;
+    s.ws_bytes = (size_t)s.n_split * s.n_jt * 8 * nblkw * 64 * sizeof(f32x4);
+#ifdef UAVGEMM_STAMPS
+    s.ws_bytes += (size_t)s.n_split * s.n_jt * 8 * 4 * sizeof(unsigned long long);
+#endif
     return s;
 }
 }  // namespace
@@ -419,49 +679,76 @@ extern "C" size_t uavagent_gemm_tn_workspace_bytes(int64_t m_rows, int32_t n_j) 
 extern "C" int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_rows, int32_t n_i, int32_t n_j, int64_t ldb, float *c, int64_t ldc,
                                     float *dbias_out, void *workspace, size_t workspace_bytes, void *stream) {
     if (!a || !b || !c || !workspace) return fail3(UAVAGENT_E_INVALID, "gemm_tn: null pointer");
-    if (m_rows < 1 || n_i < 4 || n_i > 200 || (n_i & 3) || n_j < 1 || n_j > 640 || ldb < n_j || ldc < n_j)
-        return fail3(UAVAGENT_E_INVALID, "gemm_tn: need m_rows >= 1, n_i % 4 == 0 in [4, 200], 1 <= n_j <= 640, ldb >= n_j, ldc >= n_j");
+    if (m_rows < 1 || n_i < 4 || n_i > 200 || (n_i & 3) || n_j < 1 || n_j > 640 || ldb < n_j || ldc < n_j || ldb > 65536)
+        return fail3(UAVAGENT_E_INVALID, "gemm_tn: need m_rows >= 1, n_i % 4 == 0 in [4, 200], 1 <= n_j <= 640, n_j <= ldb <= 65536, ldc >= n_j");
     if (!aligned16(a) || !aligned16(workspace)) return fail3(UAVAGENT_E_INVALID, "gemm_tn: a and workspace must be 16-byte aligned");
     const TnShape s = tn_shape(m_rows, n_j);
     if (workspace_bytes < s.ws_bytes) return fail3(UAVAGENT_E_INVALID, "gemm_tn: workspace smaller than uavagent_gemm_tn_workspace_bytes()");
     hipStream_t st = (hipStream_t)stream;
     f32x4 *slabs = reinterpret_cast<f32x4 *>(workspace);
-    const bool bvec = aligned16(b) && (ldb % 4 == 0) && (n_j % 4 == 0);
-    const dim3 grid((unsigned)(s.n_split * s.n_jt)), blk(256);
-    if (s.ncb == 13) {
-        if (bvec) hipLaunchKernelGGL((gemm_tn_kernel<13, true>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs);
-        else hipLaunchKernelGGL((gemm_tn_kernel<13, false>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs);
-        const int n_thr = s.n_jt * 4 * TnPlan<13>::NBLK * 64;
-        hipLaunchKernelGGL((gemm_tn_reduce<13>), dim3((n_thr + 255) / 256), dim3(256), 0, st, slabs, s.n_split, s.n_jt, n_i, n_j, c, (long long)ldc, dbias_out);
-    } else {
-        if (bvec) hipLaunchKernelGGL((gemm_tn_kernel<10, true>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs);
-        else hipLaunchKernelGGL((gemm_tn_kernel<10, false>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs);
-        const int n_thr = s.n_jt * 4 * TnPlan<10>::NBLK * 64;
-        hipLaunchKernelGGL((gemm_tn_reduce<10>), dim3((n_thr + 255) / 256), dim3(256), 0, st, slabs, s.n_split, s.n_jt, n_i, n_j, c, (long long)ldc, dbias_out);
-    }
+    // float4 staging of b: rows start on 16-byte boundaries and the columns up to the next multiple of 4 past n_j exist (inside the row
+    // stride) -- they must hold finite values (the learner keeps its [M, 625] logits in rows of 640 with a zero tail)
+    const bool bvec = aligned16(b) && (ldb % 4 == 0) && (ldb >= ((n_j + 3) & ~3));
+    const dim3 grid((unsigned)(s.n_split * s.n_jt)), blk(512);
+    int dbg = 0;
+#ifdef UAVGEMM_STAMPS
+    if (const char *e = std::getenv("UAVGEMM_DBG")) dbg = std::atoi(e);     // diagnostic build only: read per call
+#endif
+#define UAV_TN(PLAN_)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (bvec) hipLaunchKernelGGL((gemm_tn_kernel<PLAN_, true>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs, dbg); \
+        else hipLaunchKernelGGL((gemm_tn_kernel<PLAN_, false>), grid, blk, 0, st, a, n_i, b, (long long)ldb, n_j, (long long)m_rows, s.rows_per_split, s.n_jt, s.n_split, slabs, dbg);    \
+        const int n_items = s.n_jt * 8 * TnPlan<PLAN_>::NBLKW * 64;                                                                          \
+        hipLaunchKernelGGL((gemm_tn_reduce<PLAN_>), dim3((n_items + 63) / 64), dim3(256), 0, st, slabs, s.n_split, s.n_jt, n_i, n_j, c, (long long)ldc, dbias_out); \
+    } while (0)
+    if (s.plan == 13) UAV_TN(13); else UAV_TN(20);
+#undef UAV_TN
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_tn: launch failed");
     return UAVAGENT_OK;
 }
 
+extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
+    if (m_rows < 1) return 0;
+    return (size_t)((m_rows + kRowsBM - 1) / kRowsBM) * kNP * sizeof(float);
+}
+
 extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t ldw, int32_t w_transposed, int64_t m_rows, int32_t k,
                                       int32_t n, const float *bias, int32_t relu6, const float *relu6_mask_h, int64_t ldh, float *c, int64_t ldc,
-                                      void *stream) {
+                                      float *colsum_out, void *workspace, size_t workspace_bytes, void *stream) {
     if (!a || !w || !c) return fail3(UAVAGENT_E_INVALID, "gemm_rows: null pointer");
-    if (m_rows < 1 || k < 1 || n < 1 || n > 208 || lda < k || ldc < n || ldw < (w_transposed ? k : n))
-        return fail3(UAVAGENT_E_INVALID, "gemm_rows: need m_rows, k >= 1, 1 <= n <= 208, lda >= k, ldc >= n, ldw >= the row length of w");
+    if (m_rows < 1 || k < 1 || n < 1 || n > 208 || lda < k || ldc < n || ldw < (w_transposed ? k : n) || lda > 65536 || ldw > 65536)
+        return fail3(UAVAGENT_E_INVALID, "gemm_rows: need m_rows, k >= 1, 1 <= n <= 208, k <= lda <= 65536, ldc >= n, row length of w <= ldw <= 65536");
     if (relu6_mask_h && (bias || relu6)) return fail3(UAVAGENT_E_INVALID, "gemm_rows: the relu6-mask epilogue excludes bias / relu6");
     if (relu6_mask_h && ldh < n) return fail3(UAVAGENT_E_INVALID, "gemm_rows: ldh < n");
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = aligned16(a) && aligned16(w) && (lda % 4 == 0) && (ldw % 4 == 0) && (k % 4 == 0) && (n % 4 == 0);
+    const bool vec = aligned16(a) && aligned16(w) && aligned16(c) && aligned16(bias) && aligned16(relu6_mask_h) && (lda % 4 == 0) && (ldw % 4 == 0) &&
+                     (ldc % 4 == 0) && (ldh % 4 == 0) && (k % 4 == 0) && (n % 4 == 0);
     const dim3 grid((unsigned)((m_rows + kRowsBM - 1) / kRowsBM)), blk(256);
     const int epi = relu6_mask_h ? 2 : ((bias || relu6) ? 1 : 0);
-#define UAV_ROWS(NT_, VEC_, EPI_) hipLaunchKernelGGL((gemm_rows_kernel<NT_, VEC_, EPI_>), grid, blk, 0, st, a, (long long)lda, w, (long long)ldw, \
-        (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc)
-#define UAV_ROWS_E(NT_, VEC_) do { if (epi == 0) UAV_ROWS(NT_, VEC_, 0); else if (epi == 1) UAV_ROWS(NT_, VEC_, 1); else UAV_ROWS(NT_, VEC_, 2); } while (0)
-    if (w_transposed) { if (vec) UAV_ROWS_E(true, true); else UAV_ROWS_E(true, false); }
-    else { if (vec) UAV_ROWS_E(false, true); else UAV_ROWS_E(false, false); }
+    float *colp = nullptr;
+    if (colsum_out) {
+        if (!vec) return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums need the aligned path (16-byte aligned operands, strides / k / n multiples of 4)");
+        if (!workspace || !aligned16(workspace) || workspace_bytes < uavagent_gemm_rows_workspace_bytes(m_rows))
+            return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums need a 16-byte aligned workspace of uavagent_gemm_rows_workspace_bytes()");
+        colp = reinterpret_cast<float *>(workspace);
+    }
+#define UAV_ARGS grid, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc
+#define UAV_ROWS_E(NT_)                                                                                              \
+    do {                                                                                                             \
+        if (vec) {                                                                                                   \
+            if (epi == 0) hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 0>), UAV_ARGS, colp);                         \
+            else if (epi == 1) hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 1>), UAV_ARGS, colp);                    \
+            else hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 2>), UAV_ARGS, colp);                                  \
+        } else {                                                                                                     \
+            if (epi == 0) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 0>), UAV_ARGS);                            \
+            else if (epi == 1) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 1>), UAV_ARGS);                       \
+            else hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 2>), UAV_ARGS);                                     \
+        }                                                                                                            \
+    } while (0)
+    if (w_transposed) UAV_ROWS_E(true); else UAV_ROWS_E(false);
 #undef UAV_ROWS_E
-#undef UAV_ROWS
+#undef UAV_ARGS
+    if (colp) hipLaunchKernelGGL(rows_colsum_reduce, dim3((n + 63) / 64), dim3(1024), 0, st, colp, (long long)grid.x, (int)n, colsum_out);
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: launch failed");
     return UAVAGENT_OK;
 }

@@ -65,13 +65,13 @@ __global__ __launch_bounds__(256) void obs_indices_kernel(const int16_t *__restr
 // strided direct loads are served by the vector L1 once the first lane's line is in; not kept.)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int PER>
-__global__ __launch_bounds__(256) void sample_actions_kernel(const float *__restrict__ logits, const float *__restrict__ uni,
+__global__ __launch_bounds__(256) void sample_actions_kernel(const float *__restrict__ logits, long long ld, const float *__restrict__ uni,
                                                              long long N, int A, long long *__restrict__ action,
                                                              float *__restrict__ prob) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
-    const float *row = logits + r * A;
+    const float *row = logits + r * ld;
     float v[PER];
     float mx = -3.0e38f;
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float *__rest
 template <int PER>
 __global__ __launch_bounds__(256) void a2c_loss_grad_kernel(float *__restrict__ logits, const float *__restrict__ v,
                                                             const float *__restrict__ target, const long long *__restrict__ act,
-                                                            long long M, int A, float beta, float inv_m, float *__restrict__ dv,
+                                                            long long M, int A, long long ld, float beta, float inv_m, float *__restrict__ dv,
                                                             float *__restrict__ col_partial, double *__restrict__ loss_partial) {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void a2c_loss_grad_kernel(float *__restrict__ 
     for (int k = 0; k < PER; ++k) csum[k] = 0.f;
     double la = 0.0, lc = 0.0, sdv = 0.0;
     for (long long r = wave; r < M; r += n_waves) {
-        float *row = logits + r * A;
+        float *row = logits + r * ld;
         float p[PER];
         float mx = -3.0e38f;
 #pragma unroll
@@ -533,15 +533,16 @@ extern "C" int uavagent_obs_indices(const int16_t *ue_xy, const int32_t *bs_xy, 
     return launch_ok("obs_indices");
 }
 
-extern "C" int uavagent_sample_actions(const float *logits, const float *uniforms, int64_t n_rows, int32_t n_actions,
+extern "C" int uavagent_sample_actions(const float *logits, int64_t ld_logits, const float *uniforms, int64_t n_rows, int32_t n_actions,
                                        int64_t *actions_out, float *prob_out, void *stream) {
-    if (n_rows < 0 || n_actions < 1 || n_actions > 1024) return fail2(UAVAGENT_E_INVALID, "sample_actions: need 1 <= n_actions <= 1024");
+    if (n_rows < 0 || n_actions < 1 || n_actions > 1024 || ld_logits < n_actions)
+        return fail2(UAVAGENT_E_INVALID, "sample_actions: need 1 <= n_actions <= 1024 and ld_logits >= n_actions");
     if (n_rows == 0) return UAVAGENT_OK;
     if (!logits || !uniforms || !actions_out) return fail2(UAVAGENT_E_INVALID, "sample_actions: null pointer");
     const dim3 grid((unsigned)((n_rows + 3) / 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     long long *ao = reinterpret_cast<long long *>(actions_out);
-#define UAVAGENT_SAMPLE(P_) hipLaunchKernelGGL((sample_actions_kernel<P_>), grid, blk, 0, s, logits, uniforms, (long long)n_rows, (int)n_actions, ao, prob_out)
+#define UAVAGENT_SAMPLE(P_) hipLaunchKernelGGL((sample_actions_kernel<P_>), grid, blk, 0, s, logits, (long long)ld_logits, uniforms, (long long)n_rows, (int)n_actions, ao, prob_out)
     switch (per_lane_cols(n_actions)) {
         case 1: UAVAGENT_SAMPLE(1); break;
         case 2: UAVAGENT_SAMPLE(2); break;
@@ -559,10 +560,11 @@ extern "C" size_t uavagent_loss_grad_workspace_bytes(int32_t n_actions) {
     return up256(waves * (size_t)n_actions * sizeof(float)) + up256(waves * 3 * sizeof(double));
 }
 
-extern "C" int uavagent_a2c_loss_grad(float *logits_inout, const float *v, const float *v_target, const int64_t *actions,
+extern "C" int uavagent_a2c_loss_grad(float *logits_inout, int64_t ld_logits, const float *v, const float *v_target, const int64_t *actions,
                                       int64_t m_rows, int32_t n_actions, float beta, float *dv_out, float *dbias_out,
                                       double *loss_out, void *workspace, void *stream) {
-    if (m_rows < 1 || n_actions < 1 || n_actions > 1024) return fail2(UAVAGENT_E_INVALID, "a2c_loss_grad: need m_rows >= 1, 1 <= n_actions <= 1024");
+    if (m_rows < 1 || n_actions < 1 || n_actions > 1024 || ld_logits < n_actions)
+        return fail2(UAVAGENT_E_INVALID, "a2c_loss_grad: need m_rows >= 1, 1 <= n_actions <= 1024, ld_logits >= n_actions");
     if (!logits_inout || !v || !v_target || !actions || !dv_out || !dbias_out || !loss_out || !workspace)
         return fail2(UAVAGENT_E_INVALID, "a2c_loss_grad: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -572,7 +574,7 @@ extern "C" int uavagent_a2c_loss_grad(float *logits_inout, const float *v, const
     const float inv_m = 1.0f / (float)m_rows;
     const long long *ac = reinterpret_cast<const long long *>(actions);
 #define UAVAGENT_LOSS(P_) hipLaunchKernelGGL((a2c_loss_grad_kernel<P_>), dim3(kLossBlocks), dim3(256), 0, s, logits_inout, v, v_target, ac, \
-                                             (long long)m_rows, (int)n_actions, beta, inv_m, dv_out, colp, lossp)
+                                             (long long)m_rows, (int)n_actions, (long long)ld_logits, beta, inv_m, dv_out, colp, lossp)
     switch (per_lane_cols(n_actions)) {
         case 1: UAVAGENT_LOSS(1); break;
         case 2: UAVAGENT_LOSS(2); break;

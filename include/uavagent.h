@@ -23,7 +23,7 @@ extern "C" {
 #define UAVAGENT_E_INVALID (-1)
 #define UAVAGENT_E_HIP (-3)
 
-int uavagent_abi_version(void);   /* 2 */
+int uavagent_abi_version(void);   /* 3 */
 const char *uavagent_last_error(void);
 
 /* out_a[m, :] = sum_k w_a[idx[m, k], :] + bias_a   (k ascending, fp32; bias added last, like embedding_bag(...) + b)
@@ -50,20 +50,21 @@ int uavagent_obs_indices(const int16_t *ue_xy, const int32_t *bs_xy, const int8_
                          int32_t n_bs, int32_t grid, int64_t *idx_out, void *stream);
 
 /* choose_action (main.py:165-169): p = softmax(logits[n, :]); np.random.choice(n_actions, p=p) with the uniform u[n] supplied by
- * the caller: the first a with cumsum(p)[a] > u[n] * cumsum(p)[-1].  logits f32 [n_rows, n_actions], uniforms f32 [n_rows] in
- * [0, 1), actions_out int64 [n_rows]; prob_out f32 [n_rows, n_actions] or NULL.  n_actions <= 1024. */
-int uavagent_sample_actions(const float *logits, const float *uniforms, int64_t n_rows, int32_t n_actions, int64_t *actions_out,
-                            float *prob_out, void *stream);
+ * the caller: the first a with cumsum(p)[a] > u[n] * cumsum(p)[-1].  logits f32 [n_rows, n_actions] with row stride ld_logits floats
+ * (ABI 3: the learner keeps its 625 logits in rows of 640), uniforms f32 [n_rows] in [0, 1), actions_out int64 [n_rows]; prob_out f32
+ * [n_rows, n_actions] contiguous or NULL.  n_actions <= 1024. */
+int uavagent_sample_actions(const float *logits, int64_t ld_logits, const float *uniforms, int64_t n_rows, int32_t n_actions,
+                            int64_t *actions_out, float *prob_out, void *stream);
 
-/* Loss of main.py:64-74 and its gradient, one pass.  IN: logits [m_rows, n_actions] (actor output before the softmax), v and
+/* Loss of main.py:64-74 and its gradient, one pass.  IN: logits [m_rows, n_actions], row stride ld_logits (actor output before the softmax), v and
  * v_target f32 [m_rows], actions int64 [m_rows].  OUT: logits_inout overwritten with d(a_loss)/d(logits); dv_out [m_rows] =
  * d(c_loss)/dv; dbias_out [n_actions] = column sums of the logits gradient; loss_out double[3] = {a_loss, c_loss, sum(dv)}.
  *   td = v_target - v;  c_loss = mean(td^2);  a_loss = mean(-(beta * H + log(p[a] + 1e-5) * td)),  H = -sum p log(p + 1e-5),
  *   td enters a_loss as a constant (tf.stop_gradient, main.py:70). */
 size_t uavagent_loss_grad_workspace_bytes(int32_t n_actions);
-int uavagent_a2c_loss_grad(float *logits_inout, const float *v, const float *v_target, const int64_t *actions, int64_t m_rows,
-                           int32_t n_actions, float beta, float *dv_out, float *dbias_out, double *loss_out, void *workspace,
-                           void *stream);
+int uavagent_a2c_loss_grad(float *logits_inout, int64_t ld_logits, const float *v, const float *v_target, const int64_t *actions,
+                           int64_t m_rows, int32_t n_actions, float beta, float *dv_out, float *dbias_out, double *loss_out,
+                           void *workspace, void *stream);
 
 /* relu6 backwards with the bias gradient: dx[m, c] = dy[m, c] * (0 < y[m, c] < 6), dbias_out[c] = sum_m dx[m, c].
  * y, dy f32 [m_rows, n_cols] contiguous; dx_out has row stride ldx floats (>= n_cols; lets two results share one [M, 2H] buffer).
@@ -94,6 +95,34 @@ int uavagent_nstep_returns_f32(const float *rewards, const float *bootstrap, int
  *   gs = g * g_scale;  ms <- decay * ms + (1 - decay) * gs^2;  w <- w - lr * gs / sqrt(ms + epsilon). */
 int uavagent_rmsprop_tf1(float *w, float *ms, const float *g, int64_t n, float lr, float decay, float eps, float g_scale,
                          void *stream);
+
+/* ---- ABI 3: float32 MFMA GEMMs for the 200-wide layers (csrc/agent_gemm.hip; v_mfma_f32_16x16x4_f32, exact float32 products summed
+ * in k order inside a tile).  They replace torch.mm / torch.addmm in the update for the shapes the reference's network has
+ * (main.py:143-156: 200 hidden units, 625 actions); anything else stays with the BLAS library. ---- */
+
+/* Rows GEMM:  c[m, j] = epilogue( sum_k a[m, k] * wop[k, j] ),  0 <= j < n <= 208, any k.
+ *   w_transposed == 0:  wop = w,    w f32 [k, n] (row stride ldw): a layer forwards, x @ W
+ *   w_transposed != 0:  wop = w^T,  w f32 [n, k] (row stride ldw): backwards through a layer, dy @ W^T
+ *   epilogue: bias f32 [n] or NULL is added, then relu6 != 0 clamps to [0, 6] (tf.nn.relu6, main.py:147-148,153);  OR
+ *             relu6_mask_h f32 [m_rows, n] (row stride ldh) != NULL: c = (0 < h < 6) ? sum : 0 -- relu6 backwards, h the layer's output
+ *             (excludes bias / relu6).
+ *   a f32 [m_rows, k] (row stride lda), c f32 [m_rows, n] (row stride ldc).  16-byte aligned pointers with lda, ldw, ldc, ldh, k, n all
+ *   multiples of 4 take the fast path (float4 staging, coalesced epilogue); anything else is loaded dword by dword.
+ *   colsum_out f32 [n] or NULL: column sums of c as stored (the bias gradient of the layer below when c is a masked dx); fast path only,
+ *   needs `workspace` (16-byte aligned, uavagent_gemm_rows_workspace_bytes(m_rows) bytes); fixed summation order, bit-reproducible. */
+size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows);
+int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t ldw, int32_t w_transposed, int64_t m_rows, int32_t k,
+                           int32_t n, const float *bias, int32_t relu6, const float *relu6_mask_h, int64_t ldh, float *c, int64_t ldc,
+                           float *colsum_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Weight gradient:  c[i, j] = sum_m a[m, i] * b[m, j]  and, when dbias_out != NULL, dbias_out[j] = sum_m b[m, j]  (the bias gradient of
+ * the same layer: a column of ones rides along in the kernel).  a f32 [m_rows, n_i] CONTIGUOUS (n_i % 4 == 0, <= 200, 16-byte aligned),
+ * b f32 [m_rows, n_j] (row stride ldb, n_j <= 640), c f32 [n_i, n_j] (row stride ldc).  The sum over m is split over the CUs; partial
+ * sums go to `workspace` (16-byte aligned, uavagent_gemm_tn_workspace_bytes(m_rows, n_j) bytes) and a second pass adds them in a fixed
+ * order: bit-reproducible, no float atomics. */
+size_t uavagent_gemm_tn_workspace_bytes(int64_t m_rows, int32_t n_j);
+int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_rows, int32_t n_i, int32_t n_j, int64_t ldb, float *c, int64_t ldc,
+                         float *dbias_out, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

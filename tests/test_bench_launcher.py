@@ -37,6 +37,18 @@ def test_one_command_starts_and_counts_two_ranks():
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1         # ONE line, from rank 0
 
 
+def test_one_command_starts_and_counts_eight_ranks():
+    """The size of BASELINE config 4 (8 GPUs): 8 ranks spawned, every one counted, rank 7 owns envs [7 * 4096, 8 * 4096)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--rehearse-launcher"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["rehearsal"] is True and line["value"] is None
+    assert line["n_gpus"] == 8 and line["launcher"] == "self"
+    assert line["max_rank_plus_1"] == 8.0 and line["max_env_id_base"] == 7 * 4096.0
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
+
+
 def test_external_launcher_two_ranks():
     """The driver's form: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N (RANK / WORLD_SIZE from the launcher)."""
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,4 +1,4 @@
-"""GPU: the learner-side kernels of libuavagent.so (include/uavagent.h, ABI 2) against their plain PyTorch forms, and the fused
+"""GPU: the learner-side kernels of libuavagent.so (include/uavagent.h, ABI 3) against their plain PyTorch forms, and the fused
 A2C update / graph-captured rollout against the autograd / eager paths they replace.  The formulas are the reference's
 (main.py:64-74 loss, :143-156 network, :165-169 action choice, :300-301 RMSProp); TensorFlow is not installable here and the
 reference holds no fixtures for its learner, so this parity is against restatements: "parity unpinned" (DESIGN.md section 9)."""
@@ -219,6 +219,121 @@ def _twin_runners(torch, n_envs, T, **kw):
     r1 = A2CRunner(env1, rollout=T, **kw.pop("first", {}))
     r2 = A2CRunner(env2, rollout=T, **kw.pop("second", {}))
     return r1, r2
+
+
+def _rel(got, want64):
+    return float((got.double() - want64).abs().max() / want64.abs().max().clamp_min(1e-30))
+
+
+# (M, K, N): the learner's own shapes + tile tails; aligned ones take the float4 kernel, the others the dword kernel
+ROWS_SHAPES = [(1, 200, 200), (129, 200, 200), (4133, 200, 200), (1000, 640, 200), (777, 625, 200), (300, 37, 50), (513, 20, 208), (260, 204, 8)]
+
+
+@pytest.mark.parametrize("shape", ROWS_SHAPES, ids=lambda s: "M%d_K%d_N%d" % s)
+def test_gemm_rows_matches_torch_mm(shape):
+    """uavagent_gemm_rows_f32 (float32 MFMA): x @ W, dy @ W^T, + bias / relu6, relu6-backward mask, column sums -- against float64
+    products; tolerance 1e-5 of the largest output (O(1) data; torch.mm's own error on these shapes is 1e-6)."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    M, K, N = shape
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
+    x, w, wt, bias = rnd(M, K), rnd(K, N), rnd(N, K), rnd(N)
+    h = (rnd(M, N) * 4.0 + 2.0).clamp_(0.0, 6.0)
+    h[0, 0], h[M - 1, N - 1] = 0.0, 6.0                                 # exactly on the clamp: gradient 0 (strict inequalities)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    A.gemm_rows(x, w, out)
+    assert _rel(out, x.double() @ w.double()) < 1e-5
+    A.gemm_rows(x, w, out, bias=bias, relu6=True)
+    assert _rel(out, (x.double() @ w.double() + bias.double()).clamp(0.0, 6.0)) < 1e-5
+    A.gemm_rows(x, wt, out, w_transposed=True)
+    assert _rel(out, x.double() @ wt.double().t()) < 1e-5
+    want = (x.double() @ wt.double().t()) * ((h > 0) & (h < 6)).double()
+    A.gemm_rows(x, wt, out, w_transposed=True, relu6_mask_h=h)
+    assert _rel(out, want) < 1e-5
+    assert float(out[0, 0]) == 0.0 and float(out[M - 1, N - 1]) == 0.0
+    aligned = (K % 4 == 0) and (N % 4 == 0)
+    if aligned:                                                         # column sums (bias gradient) ride on the aligned kernel only
+        cs, ws = torch.empty(N, device="cuda"), A.gemm_rows_workspace(M, "cuda")
+        wide = torch.full((M, 2 * N + 8), float("nan"), device="cuda")     # C as a column slice of a wider buffer (gcat)
+        A.gemm_rows(x, wt, wide[:, N + 8:], w_transposed=True, relu6_mask_h=h, colsum_out=cs, workspace=ws)
+        assert torch.equal(wide[:, N + 8:], out) and bool(torch.isnan(wide[:, :N + 8]).all())
+        assert float((cs.double() - want.sum(dim=0)).abs().max()) < 1e-5 * max(1.0, float(want.abs().sum(dim=0).max()))
+        cs2 = torch.empty_like(cs)
+        A.gemm_rows(x, wt, wide[:, N + 8:], w_transposed=True, relu6_mask_h=h, colsum_out=cs2, workspace=ws)
+        assert torch.equal(cs, cs2)                                      # fixed summation order
+    else:
+        with pytest.raises(A.UavAgentError):
+            A.gemm_rows(x, wt, out, w_transposed=True, colsum_out=torch.empty(N, device="cuda"), workspace=A.gemm_rows_workspace(M, "cuda"))
+    with pytest.raises(A.UavAgentError):
+        A.gemm_rows(x, wt, out, w_transposed=True, bias=bias, relu6_mask_h=h)
+    with pytest.raises(A.UavAgentError):
+        A.gemm_rows(x, rnd(N + 1, K), out, w_transposed=True)
+
+
+# (M, I, J, ldb): J <= 208 runs plan 13, wider plan 20; ldb > J = a column slice of a padded buffer (the learner's logits: 625 of 640)
+TN_SHAPES = [(1, 200, 200, 200), (31, 200, 200, 200), (5000, 200, 200, 200), (40037, 200, 200, 200), (3000, 200, 625, 640), (2999, 200, 625, 625),
+             (700, 200, 640, 640), (1500, 64, 100, 100), (900, 200, 321, 324), (1200, 8, 5, 5)]
+
+
+@pytest.mark.parametrize("shape", TN_SHAPES, ids=lambda s: "M%d_I%d_J%d_ld%d" % s)
+def test_gemm_tn_matches_torch_mm_and_is_bit_reproducible(shape):
+    """uavagent_gemm_tn_f32: x^T dy with the bias gradient (column sums of dy) from the ones column, split over the CUs and reduced
+    in a fixed order."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    M, I, J, ldb = shape
+    g = torch.Generator(device="cuda").manual_seed(M + I + J)
+    x = torch.rand((M, I), device="cuda", generator=g) * 2.0 - 1.0
+    full = torch.zeros((M, ldb), device="cuda")
+    full[:, :J] = torch.rand((M, J), device="cuda", generator=g) * 2.0 - 1.0
+    y = full[:, :J]
+    ws = A.gemm_tn_workspace(M, J, "cuda")
+    out, db = torch.full((I, J), float("nan"), device="cuda"), torch.full((J,), float("nan"), device="cuda")
+    A.gemm_tn(x, y, out, ws, dbias_out=db)
+    want = x.double().t() @ y.double()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((out.double() - want).abs().max()) < 1e-5 * scale
+    assert float((db.double() - y.double().sum(dim=0)).abs().max()) < 1e-5 * max(1.0, float(y.double().abs().sum(dim=0).max()))
+    out2, db2 = torch.empty_like(out), torch.empty_like(db)
+    A.gemm_tn(x, y, out2, ws, dbias_out=db2)
+    assert torch.equal(out, out2) and torch.equal(db, db2)
+    A.gemm_tn(x, y, out2, ws)                                            # without the bias output: same product
+    assert torch.equal(out, out2)
+    with pytest.raises(A.UavAgentError):
+        A.gemm_tn(x, y, out, torch.empty(16, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(A.UavAgentError):
+        A.gemm_tn(x, y, torch.empty((I, J + 1), device="cuda"), ws)
+
+
+def test_update_with_hip_gemms_matches_the_update_with_torch_gemms():
+    """The same fused update with the dense layers through libuavagent's MFMA kernels (relu6 masks and bias gradients fused) and
+    through torch.mm + separate relu6-backward passes: every gradient within float32 summation-order noise, and the HIP form is
+    bit-reproducible."""
+    torch = _torch()
+    r1, r2 = _twin_runners(torch, 700, 5, first=dict(hip_gemms=True, collect_launch="eager"), second=dict(hip_gemms=False, collect_launch="eager"))
+    assert r1.hip_gemms and not r2.hip_gemms
+    for it in range(2):
+        b1, b2 = r1.collect(), r2.collect()
+        for x, y in zip(b1, b2):
+            assert torch.equal(x, y)
+        if it == 1:
+            r1._fwd_valid = r2._fwd_valid = False      # round 2: both recompute the forward pass (the HIP form with its own GEMM)
+        s1, s2 = r1.update(*b1), r2.update(*b2)
+        assert s1["hip_gemms"] and not s2["hip_gemms"]
+        np.testing.assert_allclose([s1["a_loss"], s1["c_loss"]], [s2["a_loss"], s2["c_loss"]], rtol=1e-5)
+        for k in r1.flat.gv:
+            g1, g2 = r1.flat.gv[k], r2.flat.gv[k]
+            torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-5 * float(g2.abs().max()) + 1e-12, msg=lambda m: "%s: %s" % (k, m))
+        r2.flat.w.copy_(r1.flat.w)                     # keep the twins in lockstep for round 2
+        r2.flat.ms.copy_(r1.flat.ms)
+    # bit-reproducibility proper: two fresh twins, both HIP
+    r3, r4 = _twin_runners(torch, 300, 4, first=dict(hip_gemms=True), second=dict(hip_gemms=True))
+    for _ in range(2):
+        r3.train_rollout(), r4.train_rollout()
+        assert torch.equal(r3.flat.g, r4.flat.g) and torch.equal(r3.flat.w, r4.flat.w)
 
 
 def test_fused_update_matches_the_autograd_update():

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""A few launches of each hand-written GEMM for rocprofv3 (tools/r03_gemm_prof.sh)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from drl_uav_cellularnet_amd import _agent_capi as A
+dev = torch.device("cuda", 0)
+M, H, NA = 409600, 200, 625
+g = torch.Generator(device=dev).manual_seed(5)
+rnd = lambda *s: torch.rand(s, device=dev, generator=g) * 2.0 - 1.0
+x, y = rnd(M, H), rnd(M, H)
+dl = torch.zeros(M, 640, device=dev); dl[:, :NA] = rnd(M, NA)
+h = (rnd(M, H) * 4.0 + 2.0).clamp_(0.0, 6.0)
+w2, b2 = rnd(H, H) * 0.1, rnd(H)
+w3p = torch.zeros(H, 640, device=dev); w3p[:, :NA] = rnd(H, NA) * 0.1
+out = torch.empty(M, H, device=dev)
+gw2, gw3, gb2, gb3 = torch.empty(H, H, device=dev), torch.empty(H, NA, device=dev), torch.empty(H, device=dev), torch.empty(NA, device=dev)
+ws200, ws625 = A.gemm_tn_workspace(M, H, dev), A.gemm_tn_workspace(M, NA, dev)
+reps = int(os.environ.get("REPS", "5"))
+for _ in range(reps):
+    A.gemm_rows(x, w2, out, bias=b2, relu6=True)
+    A.gemm_rows(y, w2, out, w_transposed=True)
+    A.gemm_rows(y, w2, out, w_transposed=True, relu6_mask_h=h)
+    A.gemm_rows(dl, w3p, out, w_transposed=True)
+    A.gemm_tn(x, y, gw2, ws200, dbias_out=gb2)
+    A.gemm_tn(x, dl[:, :NA], gw3, ws625, dbias_out=gb3)
+torch.cuda.synchronize()
+print("ok")
