@@ -350,6 +350,11 @@ class A2CRunner:
             self._ldl = (NA + 15) // 16 * 16
             self._logits_pad = torch.zeros((T, N, self._ldl), dtype=torch.float32, device=self.dev)
             self._fwd = {"h1a": f(T, N, H), "h1c": f(T, N, H), "h2a": f(T, N, H), "logits": self._logits_pad[:, :, :NA]}
+            # the actor's dense layers handed to uavagent_gemm_rows_f32 in its fast form: W^T (k-contiguous rows), the policy head
+            # padded to LDL rows / bias entries of zeros (so the tail of every logits row comes out zero); refreshed from the
+            # parameters at the start of every collect()
+            self._wt = {"a_w2t": f(H, H), "a_w3t": torch.zeros((self._ldl, H), dtype=torch.float32, device=self.dev),
+                        "a_b3p": torch.zeros(self._ldl, dtype=torch.float32, device=self.dev)} if self.hip_gemms else None
         self._fwd_valid = False
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
         # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
@@ -392,12 +397,17 @@ class A2CRunner:
         if cuda:
             from . import _agent_capi as A
         fw = self._fwd
+        wt = self._wt if cuda else None
         for t in range(T):
             if cuda:
                 A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
                                   out_c=fw["h1c"][t])
-                torch.addmm(net.a_b2, fw["h1a"][t], net.a_w2, out=fw["h2a"][t]).clamp_(0.0, 6.0)
-                torch.addmm(net.a_b3, fw["h2a"][t], net.a_w3, out=fw["logits"][t])
+                if wt is not None:       # float32 MFMA kernels, bias / relu6 fused, 64-row workgroups (8192 rows fill the chip)
+                    A.gemm_rows(fw["h1a"][t], wt["a_w2t"], fw["h2a"][t], w_transposed=True, bias=net.a_b2, relu6=True)
+                    A.gemm_rows(fw["h2a"][t], wt["a_w3t"], self._logits_pad[t], w_transposed=True, bias=wt["a_b3p"])
+                else:
+                    torch.addmm(net.a_b2, fw["h1a"][t], net.a_w2, out=fw["h2a"][t]).clamp_(0.0, 6.0)
+                    torch.addmm(net.a_b3, fw["h2a"][t], net.a_w3, out=fw["logits"][t])
                 A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
             else:
                 prob = net.actor_only(self.idx_buf[t])
@@ -411,6 +421,7 @@ class A2CRunner:
         until the next collect()."""
         env, T = self.env, self.T
         self.u_buf.copy_(torch.rand(self.u_buf.shape, device=self.dev, dtype=torch.float32, generator=self.gen))
+        self._refresh_transposed()
         if self.collect_launch == "graph" and self.dev.type == "cuda" and self._graph is None:
             try:
                 self._capture()
@@ -437,6 +448,16 @@ class A2CRunner:
             env.reset(mask=done)
             self._indices_into(self.idx_buf[T])
         return self.idx_buf[:T], self.act_buf, self.rew_buf, boot
+
+    def _refresh_transposed(self):
+        """The transposed / padded copies of the actor's dense layers the rollout's GEMM kernel reads (three small copies; the captured
+        graph reads the same buffers)."""
+        wt = getattr(self, "_wt", None)
+        if wt is not None:
+            net = self.net
+            wt["a_w2t"].copy_(net.a_w2.t())
+            wt["a_w3t"][:net.n_action].copy_(net.a_w3.t())
+            wt["a_b3p"][:net.n_action].copy_(net.a_b3)
 
     def _capture(self):
         """hipGraph of the rollout loop.  A warm-up pass on a side stream first (rocBLAS handles / workspaces), on a CLONE of the
@@ -533,10 +554,12 @@ class A2CRunner:
         if not reuse:
             A.sparse_rows_sum(idx, net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=b["h1a"], out_c=b["h1c"])
             if hip:
-                A.gemm_rows(b["h1a"], net.a_w2, b["h2a"], bias=net.a_b2, relu6=True)
+                self._refresh_transposed()
+                A.gemm_rows(b["h1a"], self._wt["a_w2t"], b["h2a"], w_transposed=True, bias=net.a_b2, relu6=True)
+                A.gemm_rows(b["h2a"], self._wt["a_w3t"], b["logits_pad"], w_transposed=True, bias=self._wt["a_b3p"])
             else:
                 torch.addmm(net.a_b2, b["h1a"], net.a_w2, out=b["h2a"]).clamp_(0.0, 6.0)
-            torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
+                torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
         self._fwd_valid = False                                        # the backward pass below overwrites logits and h2a
         if hip:
             A.gemm_rows(b["h1c"], net.c_w2, b["h2c"], bias=net.c_b2, relu6=True)

@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "../../include/uavagent.h"
 #include "agent_common.h"
@@ -28,6 +29,7 @@ namespace {
 int fail3(int code, const std::string &msg) { return uavagent_internal::fail(code, msg); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int kNP = 208;        // 200 padded to 13 column blocks; 208 = 6 x 32 + 16 floats: rows of an [k][208] LDS tile start 16 banks
@@ -41,6 +43,11 @@ constexpr int kRB = 13;         // 16-row blocks of the 200-wide dimension
 // every load before the first MFMA.)
 __device__ __forceinline__ float mask_f(float v, bool ok) { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); }
 __device__ __forceinline__ float4 mask_f4(float4 v, bool ok) { return float4{mask_f(v.x, ok), mask_f(v.y, ok), mask_f(v.z, ok), mask_f(v.w, ok)}; }
+// "This value has arrived": waits for every outstanding load and hands the registers back as the asm's own outputs, so that hipcc no
+// longer attaches a pending load to them.  Without it a value loaded ahead of a store loop (bias, the relu6 mask's H rows) drags an
+// s_waitcnt vmcnt(0) into every iteration behind a branch -- which also waits for the PREVIOUS iteration's store: 16 serialised store
+// round trips per workgroup (the epilogue of the first versions: 15 000 cycles of a 124 000-cycle workgroup, profiles/r03m_*).
+__device__ __forceinline__ void arrived4(float4 &v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ float4 ldraw4(const float *p, bool ok, const float *safe) { return *reinterpret_cast<const float4 *>(ok ? p : safe); }
 __device__ __forceinline__ float ldraw1(const float *p, bool ok, const float *safe) { return *(ok ? p : safe); }
 
@@ -542,6 +549,372 @@ __global__ __launch_bounds__(1024) void rows_colsum_reduce(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dy @ W^T (and x @ W with W handed over transposed), version 3: BOTH tiles k-contiguous in LDS, rows of 24 floats (20 k of a chunk + 4
+// padding: with this stride the sixteen 16-byte pieces a ds_read_b128 lane group touches fall on 16 different bank quads).  A lane
+// (r, q) then takes its operands of FOUR k-steps with one ds_read_b128 (k = 4 q + s for k-step s: any bijection of k serves as long as
+// both operands use it) and the fifth with a ds_read_b32 (k = 16 + q): 2 LDS reads per 5 MFMAs of a block instead of 5.  An in-order
+// wave pays ~4 cycles of MFMA issue for every LDS read between two MFMAs (s_memtime stamps on the dW kernel: 37 cycles per MFMA with one
+// read per gap, against the pipe's 32), and the partner wave of the SIMD cannot use those gaps.
+//   BM = 128: 4 waves x 32 rows x NB column blocks, 2 workgroups per CU (the update: M = rollout x envs rows);
+//   BM =  64: 4 waves x 16 rows x NB column blocks, N cut into slices of NB blocks across blockIdx.y (the rollout's M = envs rows: 8192 rows
+//             give 256 / 512 workgroups at NB = 7 / 10).
+// Epilogues as gemm_rows_vec_kernel; the column sums (col_partial) exist for single-slice launches only.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kNtBK = 20, kNtLD = 24;
+
+template <int BM, int NB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_rows_nt_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+                                                               int K, int N, long long M, const float *__restrict__ bias, int relu6,
+                                                               const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc,
+                                                               float *__restrict__ col_partial) {
+    static_assert(BM == 128 || BM == 64, "wave tile = 32 or 16 rows");
+    constexpr int RBW = BM / 64;                                   // 16-row blocks per wave
+    constexpr int A_TILE = BM * kNtLD, W_TILE = NB * 16 * kNtLD;
+    constexpr int LDC = NB * 16 + 4;                               // epilogue staging row stride (16-byte multiple)
+    constexpr int LDS_FLOATS = (2 * (A_TILE + W_TILE) > 4 * 16 * LDC) ? 2 * (A_TILE + W_TILE) : 4 * 16 * LDC;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *const sA = lds, *const sW = lds + 2 * A_TILE;
+    unsigned long long ts0 = 0, ts1 = 0, tsa = 0, tsb = 0, tsc = 0, t_mfma = 0, t_bound = 0, ts2 = 0, ts3 = 0;
+    (void)ts0; (void)ts1; (void)tsa; (void)tsb; (void)tsc; (void)t_mfma; (void)t_bound; (void)ts2; (void)ts3;
+    GEMM_STAMP(ts0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * NB * 16;                           // this workgroup's slice of the output columns
+    const int nloc = (N - n0 < NB * 16) ? N - n0 : NB * 16;
+
+    // staging plan: float4 number c4 (k = 4 c4 ..) of tile row `row`; raw loads from safe addresses, zeroed at the LDS store
+    constexpr int NA = (BM * 5 + 255) / 256, NW = (NB * 16 * 5 + 255) / 256;
+    int a_g[NA], a_l[NA], w_g[NW], w_l[NW];
+    bool a_ok[NA], w_ok[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + 256 * i, row = idx / 5, c4 = idx - row * 5;
+        a_g[i] = row * (int)lda + c4 * 4; a_l[i] = (idx < BM * 5) ? row * kNtLD + c4 * 4 : -1;
+        a_ok[i] = (idx < BM * 5) && (m0 + row < M);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + 256 * i, row = idx / 5, c4 = idx - row * 5;
+        w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = (idx < NB * 16 * 5) ? row * kNtLD + c4 * 4 : -1;
+        w_ok[i] = (idx < NB * 16 * 5) && (row < nloc);
+    }
+    float4 va[NA], vw[NW];
+    const float *gA = A + m0 * lda, *gW = W + (long long)n0 * ldw;
+    auto load_chunk = [&](int c) {
+        const int k0 = c * kNtBK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[i] = ldraw4(gA + k0 + a_g[i], a_ok[i] && (k0 + (a_l[i] % kNtLD) < K), A);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) vw[i] = ldraw4(gW + k0 + w_g[i], w_ok[i] && (k0 + (w_l[i] % kNtLD) < K), W);
+    };
+    auto store_chunk = [&](int buf, int c) {
+        const int k0 = c * kNtBK;
+        float *dA = sA + buf * A_TILE, *dW = sW + buf * W_TILE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (a_l[i] >= 0) *reinterpret_cast<float4 *>(dA + a_l[i]) = mask_f4(va[i], a_ok[i] && (k0 + (a_l[i] % kNtLD) < K));
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (w_l[i] >= 0) *reinterpret_cast<float4 *>(dW + w_l[i]) = mask_f4(vw[i], w_ok[i] && (k0 + (w_l[i] % kNtLD) < K));
+    };
+
+    f32x4 acc[RBW][NB];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunks = (K + kNtBK - 1) / kNtBK;
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    const int fa = (wave * (16 * RBW) + r) * kNtLD + 4 * q, fw = r * kNtLD + 4 * q;    // this lane's 16-byte piece of the first 16 k
+    const int fa5 = (wave * (16 * RBW) + r) * kNtLD + 16 + q, fw5 = r * kNtLD + 16 + q;  // and its element of the fifth k-step
+    GEMM_STAMP(ts1);
+    tsc = ts1;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        tsa = tsc;
+        if (c + 1 < n_chunks) load_chunk(c + 1);
+        const float *tA = sA + buf * A_TILE, *tW = sW + buf * W_TILE;
+        // reads in issue order: a128[*], w128[0 .. AHEAD-1]; then one read ahead of each column block (sched_barrier pins the order, see
+        // tn_ksteps): the b128 of the block AHEAD blocks on during k-step 0, the b32 operands of k-step 4 during k-steps 1 and 2
+        constexpr int AHEAD = (NB < 4) ? NB : 4;
+        f32x4 a4[RBW], w4[NB];
+        float a1[RBW], w1[NB];
+#pragma unroll
+        for (int i = 0; i < RBW; ++i) a4[i] = *reinterpret_cast<const f32x4 *>(tA + fa + i * 16 * kNtLD);
+#pragma unroll
+        for (int cb = 0; cb < AHEAD; ++cb) w4[cb] = *reinterpret_cast<const f32x4 *>(tW + fw + cb * 16 * kNtLD);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                // reads ahead: during k-step 0 the next column block's b128; during k-steps 1-3 the b32 operands of k-step 4
+                if (ks == 0 && cb + AHEAD < NB) w4[cb + AHEAD < NB ? cb + AHEAD : 0] = *reinterpret_cast<const f32x4 *>(tW + fw + (cb + AHEAD) * 16 * kNtLD);
+                if (ks == 1 && cb < RBW) a1[cb < RBW ? cb : 0] = tA[fa5 + cb * 16 * kNtLD];
+                if (ks == 2) w1[cb] = tW[fw5 + cb * 16 * kNtLD];
+#pragma unroll
+                for (int i = 0; i < RBW; ++i) {
+                    acc[i][cb] = MFMA16(ks < 4 ? a4[i][ks < 4 ? ks : 0] : a1[i], ks < 4 ? w4[cb][ks < 4 ? ks : 0] : w1[cb], acc[i][cb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        GEMM_STAMP(tsb);
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1, c + 1);
+        __syncthreads();
+        GEMM_STAMP(tsc);
+        t_mfma += tsb - tsa; t_bound += tsc - tsb;
+    }
+    GEMM_STAMP(ts2);
+
+    // ---- epilogue through LDS (see gemm_rows_vec_kernel): 16 rows x NB * 16 columns per wave and round, one whole row per instruction ----
+    float *E = lds + wave * (16 * LDC);
+    float4 cs = float4{0.f, 0.f, 0.f, 0.f};
+    const bool col_ok = lane * 4 < nloc;
+    float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1 && bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(bias + n0 + lane * 4);
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+        // the relu6 mask's H rows are requested BEFORE the staging pass and the barrier, all 16 at once: loaded inside the store loop,
+        // each batch of them exposed a full HBM round trip per workgroup (the masked dX ran 0.10-0.14 ms behind the plain one)
+        float4 hv[16];
+        if (EPI == 2) {
+#pragma unroll
+            for (int row = 0; row < 16; ++row) {
+                const long long m = m0 + wave * (16 * RBW) + rb * 16 + row;
+                hv[row] = ldraw4(H + m * ldh + n0 + lane * 4, col_ok && m < M, H);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) E[(4 * q + t) * LDC + cb * 16 + r] = acc[rb][cb][t];
+        __syncthreads();
+        if (EPI == 1) arrived4(bv);
+        if (EPI == 2) {
+#pragma unroll
+            for (int row = 0; row < 16; ++row) arrived4(hv[row]);
+        }
+#pragma unroll
+        for (int row = 0; row < 16; ++row) {
+            const long long m = m0 + wave * (16 * RBW) + rb * 16 + row;
+            if (col_ok && m < M) {
+                float4 v = *reinterpret_cast<const float4 *>(E + row * LDC + lane * 4);
+                if (EPI == 1) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (relu6) { v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f); }
+                }
+                if (EPI == 2) {
+                    const float4 h = hv[row];
+                    v.x = (h.x > 0.f && h.x < 6.f) ? v.x : 0.f; v.y = (h.y > 0.f && h.y < 6.f) ? v.y : 0.f;
+                    v.z = (h.z > 0.f && h.z < 6.f) ? v.z : 0.f; v.w = (h.w > 0.f && h.w < 6.f) ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(C + m * ldc + n0 + lane * 4) = v;
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (col_partial != nullptr) {                                          // (host: N <= 208; a slice owns its columns of the partial row)
+        float4 *S = reinterpret_cast<float4 *>(lds);                       // [4 waves][52 float4]
+        if (lane < 52) S[wave * 52 + lane] = cs;
+        __syncthreads();
+        if (wave == 0 && col_ok) {
+            float4 t = S[lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const float4 u = S[w * 52 + lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            *reinterpret_cast<float4 *>(col_partial + (long long)blockIdx.x * kNP + n0 + lane * 4) = t;
+        }
+    }
+#ifdef UAVGEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_STAMP(ts3);
+    if (col_partial != nullptr && lane == 0 && blockIdx.y == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(col_partial + (long long)gridDim.x * kNP) + ((long long)blockIdx.x * 4 + wave) * 6;
+        d[0] = ts3 - ts0; d[1] = ts1 - ts0; d[2] = t_mfma; d[3] = t_bound; d[4] = ts3 - ts2; d[5] = ts0;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dy @ W^T, version 4 (K a multiple of 40): tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass) into a ring of NSTAGE buffers, chunks of 40 k, the loads of chunk c + NSTAGE - 1 issued before chunk c is computed
+// and retired by a COUNTED s_waitcnt vmcnt + a raw s_barrier (cdna_hip_programming.md section 5, Pipelining across barriers).  What
+// the register-staged kernels above showed in s_memtime stamps (profiles/r03m_*): with a prefetch distance of one 20-k chunk a
+// workgroup spent 22 % of its life at chunk boundaries waiting for loads (80-byte pieces of 128 rows) and 9 % in its prologue -- and a
+// rollout-sized launch (64 rows per workgroup, 35 MFMAs per chunk) nearly all of it.
+// LDS image of a stage: [BM A rows | NB * 16 W rows] x 40 floats, unpadded -- lane-linear for the DMA (a wave-instruction fills 1 KiB),
+// and with a 160-byte row stride the sixteen 16-byte pieces of a ds_read_b128 lane group still fall on 16 different bank quads.  A lane
+// (r, q) reads its operands of k-steps 0-3 / 4-7 with one ds_read_b128 each (k = 4 q + s, 16 + 4 q + s) and of k-steps 8-9 with a
+// ds_read_b64 (k = 32 + 2 q + s).  One wavefront = 16 rows x NB column blocks (BM / 16 wavefronts); rows beyond M or N and the
+// padding of a stage are loaded from a 16-byte zero block.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero16[4];          // (zero-initialised: device globals are)
+constexpr int kGlBK = 40;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int NB, int NSTAGE, int EPI>
+__global__ __launch_bounds__(BM * 4) void gemm_rows_glds_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+                                                                 int K, int N, long long M, const float *__restrict__ bias, int relu6,
+                                                                 const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc,
+                                                                 float *__restrict__ col_partial) {
+    constexpr int NWAVE = BM / 16, NTHR = NWAVE * 64;
+    constexpr int ROWS = BM + NB * 16;                      // tile rows of a stage: A rows, then W rows
+    constexpr int F4 = ROWS * (kGlBK / 4);                  // float4s of a stage
+    constexpr int NL = (F4 + NTHR - 1) / NTHR;              // LDS-DMA instructions per wave and chunk
+    constexpr int STAGE_F = NL * NTHR * 4;                  // floats of a stage, padded to whole passes of the workgroup
+    constexpr int LDC = NB * 16 + 4;
+    constexpr int LDS_F = (NSTAGE * STAGE_F > NWAVE * 16 * LDC) ? NSTAGE * STAGE_F : NWAVE * 16 * LDC;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring of 2 or 3 stages");
+    static_assert((NSTAGE - 1) * NL <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * NB * 16;
+    const int nloc = (N - n0 < NB * 16) ? N - n0 : NB * 16;
+
+    // ---- per-pass DMA sources.  TWO register sets, for even and odd chunks, each advanced by two chunks (80 floats) just before it is
+    // used again: a set is then never written while an LDS-DMA that read it can still be in flight (hipcc guards such a write with
+    // s_waitcnt vmcnt(0), which would drain the ring; a temporary address register per instruction gets the same treatment as soon as
+    // it is reused) ----
+    const float *src[2][NL];
+    unsigned real = 0u;
+#pragma unroll
+    for (int p = 0; p < NL; ++p) {
+        const int idx = (p * NWAVE + wave) * 64 + lane, row = idx / (kGlBK / 4), c4 = idx - row * (kGlBK / 4);
+        const float *s = g_zero16;
+        if (row < BM) { if (m0 + row < M) { s = A + (m0 + row) * lda + c4 * 4; real |= 1u << p; } }
+        else if (row < ROWS) { if (row - BM < nloc) { s = W + (long long)(n0 + row - BM) * ldw + c4 * 4; real |= 1u << p; } }
+        src[0][p] = s;
+        src[1][p] = s + (((real >> p) & 1u) ? kGlBK : 0);
+    }
+    auto issue_chunk = [&](auto set_c, int c) {               // chunk c (parity = set) -> stage c % NSTAGE
+        constexpr int SET = decltype(set_c)::value;
+        float *stage = lds + (c % NSTAGE) * STAGE_F;
+#pragma unroll
+        for (int p = 0; p < NL; ++p) {
+            if (c >= 2) src[SET][p] += (((real >> p) & 1u) ? 2 * kGlBK : 0);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)src[SET][p], (lds_void_t *)(stage + (p * NWAVE + wave) * 256), 16, 0, 0);
+        }
+    };
+    using set0_t = std::integral_constant<int, 0>;
+    using set1_t = std::integral_constant<int, 1>;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = K / kGlBK;                          // (host: K % 40 == 0, K >= 40)
+    issue_chunk(set0_t{}, 0);
+    if (NSTAGE == 3 && n_chunks > 1) issue_chunk(set1_t{}, 1);
+    const int fa = (wave * 16 + r) * kGlBK, fw = (BM + r) * kGlBK;       // this lane's rows of the A / W part of a stage
+    auto chunk = [&](auto set_c, int c) {                     // SET = parity of chunk c + NSTAGE - 1, the one issued here
+        // chunk c has landed once at most the younger chunks' loads are outstanding; then the barrier makes every wave's part visible
+        const int younger = (n_chunks - 1 - c < NSTAGE - 2) ? n_chunks - 1 - c : NSTAGE - 2;
+        if (NSTAGE == 3 && younger == 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + NSTAGE - 1 < n_chunks) issue_chunk(set_c, c + NSTAGE - 1);   // its stage was read last in chunk c - 1: every wave is past that
+        const float *st = lds + (c % NSTAGE) * STAGE_F;
+        // group g of k: 0 = k 0-15, 1 = k 16-31 (one b128 per 16-row block), 2 = k 32-39 (one b64); group g + 1 is read while the first
+        // k-step of group g issues, one read ahead of each MFMA (sched_barrier pins the order, see tn_ksteps)
+        f32x4 a01[2], w01[2][NB];
+        f32x2 a2, w2[NB];
+        a01[0] = *reinterpret_cast<const f32x4 *>(st + fa + 4 * q);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) w01[0][cb] = *reinterpret_cast<const f32x4 *>(st + fw + cb * 16 * kGlBK + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < kGlBK / 4; ++ks) {
+            const int g = ks >> 2, e = ks & 3;
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                if (ks == 0) {                                              // reads of group 1
+                    if (cb == 0) a01[1] = *reinterpret_cast<const f32x4 *>(st + fa + 16 + 4 * q);
+                    w01[1][cb] = *reinterpret_cast<const f32x4 *>(st + fw + cb * 16 * kGlBK + 16 + 4 * q);
+                }
+                if (ks == 4) {                                              // reads of group 2
+                    if (cb == 0) a2 = *reinterpret_cast<const f32x2 *>(st + fa + 32 + 2 * q);
+                    w2[cb] = *reinterpret_cast<const f32x2 *>(st + fw + cb * 16 * kGlBK + 32 + 2 * q);
+                }
+                const float av = (g < 2) ? a01[g < 2 ? g : 0][e] : a2[e & 1];
+                const float wv = (g < 2) ? w01[g < 2 ? g : 0][cb][e] : w2[cb][e & 1];
+                acc[cb] = MFMA16(av, wv, acc[cb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // chunk c issues chunk c + NSTAGE - 1: with 2 stages that one has the other parity, with 3 the same
+    for (int c = 0; c < n_chunks; c += 2) {
+        if (NSTAGE == 2) { chunk(set1_t{}, c); if (c + 1 < n_chunks) chunk(set0_t{}, c + 1); }
+        else { chunk(set0_t{}, c); if (c + 1 < n_chunks) chunk(set1_t{}, c + 1); }
+    }
+    __syncthreads();                                          // every wave is done with the ring: the epilogue stages through it
+
+    // ---- epilogue through LDS (see gemm_rows_vec_kernel): 16 rows x NB * 16 columns per wave, one whole row per instruction ----
+    float *E = lds + wave * (16 * LDC);
+    float4 cs = float4{0.f, 0.f, 0.f, 0.f};
+    const bool col_ok = lane * 4 < nloc;
+    float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1 && bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(bias + n0 + lane * 4);
+    float4 hv[16];
+    if (EPI == 2) {
+#pragma unroll
+        for (int row = 0; row < 16; ++row) {
+            const long long m = m0 + wave * 16 + row;
+            hv[row] = ldraw4(H + m * ldh + n0 + lane * 4, col_ok && m < M, H);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) E[(4 * q + t) * LDC + cb * 16 + r] = acc[cb][t];
+    __syncthreads();
+    if (EPI == 1) arrived4(bv);
+    if (EPI == 2) {
+#pragma unroll
+        for (int row = 0; row < 16; ++row) arrived4(hv[row]);
+    }
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+        const long long m = m0 + wave * 16 + row;
+        if (col_ok && m < M) {
+            float4 v = *reinterpret_cast<const float4 *>(E + row * LDC + lane * 4);
+            if (EPI == 1) {
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (relu6) { v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f); }
+            }
+            if (EPI == 2) {
+                const float4 h = hv[row];
+                v.x = (h.x > 0.f && h.x < 6.f) ? v.x : 0.f; v.y = (h.y > 0.f && h.y < 6.f) ? v.y : 0.f;
+                v.z = (h.z > 0.f && h.z < 6.f) ? v.z : 0.f; v.w = (h.w > 0.f && h.w < 6.f) ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4 *>(C + m * ldc + n0 + lane * 4) = v;
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
+    }
+    if (col_partial != nullptr) {          // (host: N <= 208) rows ascending inside a wave, then the waves in order, then the workgroups
+        __syncthreads();
+        float4 *S = reinterpret_cast<float4 *>(lds);                       // [NWAVE][52 float4]
+        if (lane < 52) S[wave * 52 + lane] = cs;
+        __syncthreads();
+        if (wave == 0 && col_ok) {
+            float4 t = S[lane];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) { const float4 u = S[w * 52 + lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            *reinterpret_cast<float4 *>(col_partial + (long long)blockIdx.x * kNP + n0 + lane * 4) = t;
+        }
+    }
+}
+
 template <bool NT, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
                                                             int K, int N, long long M, const float *__restrict__ bias, int relu6,
@@ -709,30 +1082,44 @@ extern "C" int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_ro
 
 extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
     if (m_rows < 1) return 0;
-    return (size_t)((m_rows + kRowsBM - 1) / kRowsBM) * kNP * sizeof(float);
+    size_t b = (size_t)((m_rows + 63) / 64) * kNP * sizeof(float);          // one partial row per workgroup of the 64-row kernel (the most)
+#ifdef UAVGEMM_STAMPS
+    b += (size_t)((m_rows + 63) / 64) * 4 * 6 * sizeof(unsigned long long);
+#endif
+    return b;
 }
 
 extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t ldw, int32_t w_transposed, int64_t m_rows, int32_t k,
                                       int32_t n, const float *bias, int32_t relu6, const float *relu6_mask_h, int64_t ldh, float *c, int64_t ldc,
                                       float *colsum_out, void *workspace, size_t workspace_bytes, void *stream) {
     if (!a || !w || !c) return fail3(UAVAGENT_E_INVALID, "gemm_rows: null pointer");
-    if (m_rows < 1 || k < 1 || n < 1 || n > 208 || lda < k || ldc < n || ldw < (w_transposed ? k : n) || lda > 65536 || ldw > 65536)
-        return fail3(UAVAGENT_E_INVALID, "gemm_rows: need m_rows, k >= 1, 1 <= n <= 208, k <= lda <= 65536, ldc >= n, row length of w <= ldw <= 65536");
+    if (m_rows < 1 || k < 1 || n < 1 || n > 1024 || lda < k || ldc < n || ldw < (w_transposed ? k : n) || lda > 65536 || ldw > 65536)
+        return fail3(UAVAGENT_E_INVALID, "gemm_rows: need m_rows, k >= 1, 1 <= n <= 1024, k <= lda <= 65536, ldc >= n, row length of w <= ldw <= 65536");
     if (relu6_mask_h && (bias || relu6)) return fail3(UAVAGENT_E_INVALID, "gemm_rows: the relu6-mask epilogue excludes bias / relu6");
     if (relu6_mask_h && ldh < n) return fail3(UAVAGENT_E_INVALID, "gemm_rows: ldh < n");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = aligned16(a) && aligned16(w) && aligned16(c) && aligned16(bias) && aligned16(relu6_mask_h) && (lda % 4 == 0) && (ldw % 4 == 0) &&
                      (ldc % 4 == 0) && (ldh % 4 == 0) && (k % 4 == 0) && (n % 4 == 0);
+    if (n > 208 && !(vec && w_transposed))
+        return fail3(UAVAGENT_E_INVALID, "gemm_rows: n > 208 needs the aligned w_transposed form (N is then cut into slices)");
     const dim3 grid((unsigned)((m_rows + kRowsBM - 1) / kRowsBM)), blk(256);
     const int epi = relu6_mask_h ? 2 : ((bias || relu6) ? 1 : 0);
     float *colp = nullptr;
     if (colsum_out) {
+        if (n > 208) return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums exist for n <= 208");
         if (!vec) return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums need the aligned path (16-byte aligned operands, strides / k / n multiples of 4)");
         if (!workspace || !aligned16(workspace) || workspace_bytes < uavagent_gemm_rows_workspace_bytes(m_rows))
             return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums need a 16-byte aligned workspace of uavagent_gemm_rows_workspace_bytes()");
         colp = reinterpret_cast<float *>(workspace);
     }
 #define UAV_ARGS grid, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc
+#define UAV_NT(BM_, NB_)                                                                                             \
+    do {                                                                                                             \
+        const dim3 g2((unsigned)((m_rows + BM_ - 1) / BM_), (unsigned)((n + NB_ * 16 - 1) / (NB_ * 16)));               \
+        if (epi == 0) hipLaunchKernelGGL((gemm_rows_nt_kernel<BM_, NB_, 0>), g2, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+        else if (epi == 1) hipLaunchKernelGGL((gemm_rows_nt_kernel<BM_, NB_, 1>), g2, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+        else hipLaunchKernelGGL((gemm_rows_nt_kernel<BM_, NB_, 2>), g2, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+    } while (0)
 #define UAV_ROWS_E(NT_)                                                                                              \
     do {                                                                                                             \
         if (vec) {                                                                                                   \
@@ -745,10 +1132,37 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
             else hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 2>), UAV_ARGS);                                     \
         }                                                                                                            \
     } while (0)
-    if (w_transposed) UAV_ROWS_E(true); else UAV_ROWS_E(false);
+#define UAV_GL(BM_, NB_, NS_)                                                                                         \
+    do {                                                                                                             \
+        const dim3 g2((unsigned)((m_rows + BM_ - 1) / BM_), (unsigned)((n + NB_ * 16 - 1) / (NB_ * 16))), b2(BM_ * 4);  \
+        if (epi == 0) hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 0>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+        else if (epi == 1) hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 1>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+        else hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 2>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
+    } while (0)
+    static const int no_glds = [] { const char *e = std::getenv("UAVGEMM_NO_GLDS"); return e ? std::atoi(e) : 0; }();   // experiments only
+    if (w_transposed && vec && (k % kGlBK == 0) && !no_glds) {
+        // LDS-DMA ring (gemm_rows_glds_kernel).  Few rows (a rollout step): 64-row workgroups, N in slices; many rows: 128-row workgroups.
+        if (m_rows <= 32768) { if (n <= 224) UAV_GL(64, 7, 3); else UAV_GL(64, 10, 3); }
+        else if (n <= 208) UAV_GL(128, 13, 2);
+        else UAV_GL(128, 10, 2);
+    } else if (w_transposed && vec) {
+        // k-contiguous tiles, wide fragment reads (gemm_rows_nt_kernel).  Few rows (a rollout step): 64-row workgroups and N in slices,
+        // so that 8192 rows still give >= 256 workgroups; many rows (the update): 128-row workgroups over all <= 208 columns.
+        static const int force_bm = [] { const char *e = std::getenv("UAVGEMM_BM"); return e ? std::atoi(e) : 0; }();   // experiments only
+        if (m_rows <= 32768) { if (n <= 224) UAV_NT(64, 7); else UAV_NT(64, 10); }
+        else if (n <= 208) { if (force_bm == 64) UAV_NT(64, 13); else UAV_NT(128, 13); }
+        else UAV_NT(128, 10);
+    } else if (w_transposed) UAV_ROWS_E(true);
+    else UAV_ROWS_E(false);
+#undef UAV_NT
+#undef UAV_GL
 #undef UAV_ROWS_E
 #undef UAV_ARGS
-    if (colp) hipLaunchKernelGGL(rows_colsum_reduce, dim3((n + 63) / 64), dim3(1024), 0, st, colp, (long long)grid.x, (int)n, colsum_out);
+    if (colp) {
+        static const int force_bm2 = [] { const char *e = std::getenv("UAVGEMM_BM"); return e ? std::atoi(e) : 0; }();
+        const long long n_part = (w_transposed && (m_rows <= 32768 || force_bm2 == 64)) ? (m_rows + 63) / 64 : (long long)grid.x;     // workgroups along M of the kernel that ran
+        hipLaunchKernelGGL(rows_colsum_reduce, dim3((n + 63) / 64), dim3(1024), 0, st, colp, n_part, (int)n, colsum_out);
+    }
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: launch failed");
     return UAVAGENT_OK;
 }

@@ -226,7 +226,8 @@ def _rel(got, want64):
 
 
 # (M, K, N): the learner's own shapes + tile tails; aligned ones take the float4 kernel, the others the dword kernel
-ROWS_SHAPES = [(1, 200, 200), (129, 200, 200), (4133, 200, 200), (1000, 640, 200), (777, 625, 200), (300, 37, 50), (513, 20, 208), (260, 204, 8)]
+ROWS_SHAPES = [(1, 200, 200), (129, 200, 200), (4133, 200, 200), (1000, 640, 200), (777, 625, 200), (300, 37, 50), (513, 20, 208), (260, 204, 8),
+               (40001, 200, 200), (33000, 640, 200), (35000, 40, 64)]       # > 32768 rows: the update's 128-row kernel
 
 
 @pytest.mark.parametrize("shape", ROWS_SHAPES, ids=lambda s: "M%d_K%d_N%d" % s)
@@ -254,7 +255,7 @@ def test_gemm_rows_matches_torch_mm(shape):
     assert _rel(out, want) < 1e-5
     assert float(out[0, 0]) == 0.0 and float(out[M - 1, N - 1]) == 0.0
     aligned = (K % 4 == 0) and (N % 4 == 0)
-    if aligned:                                                         # column sums (bias gradient) ride on the aligned kernel only
+    if aligned:                                                         # column sums (bias gradient) ride on the aligned kernels only
         cs, ws = torch.empty(N, device="cuda"), A.gemm_rows_workspace(M, "cuda")
         wide = torch.full((M, 2 * N + 8), float("nan"), device="cuda")     # C as a column slice of a wider buffer (gcat)
         A.gemm_rows(x, wt, wide[:, N + 8:], w_transposed=True, relu6_mask_h=h, colsum_out=cs, workspace=ws)
@@ -266,10 +267,33 @@ def test_gemm_rows_matches_torch_mm(shape):
     else:
         with pytest.raises(A.UavAgentError):
             A.gemm_rows(x, wt, out, w_transposed=True, colsum_out=torch.empty(N, device="cuda"), workspace=A.gemm_rows_workspace(M, "cuda"))
+    if aligned:                                                         # x @ W through the transposed form: the rollout's layers
+        A.gemm_rows(x, w.t().contiguous(), out, w_transposed=True, bias=bias, relu6=True)
+        assert _rel(out, (x.double() @ w.double() + bias.double()).clamp(0.0, 6.0)) < 1e-5
     with pytest.raises(A.UavAgentError):
         A.gemm_rows(x, wt, out, w_transposed=True, bias=bias, relu6_mask_h=h)
     with pytest.raises(A.UavAgentError):
         A.gemm_rows(x, rnd(N + 1, K), out, w_transposed=True)
+
+
+def test_gemm_rows_wide_output_in_slices():
+    """The policy head forwards: [N, 200] x [200, 625] with the logits in rows of 640 -- the caller hands over W^T and the bias padded
+    to 640 rows (zeros), N is cut into slices across workgroups, and the tail of every logits row comes out exactly zero (the update's
+    GEMMs read it)."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
+    for M in (8192, 100, 40000):
+        x, w3t, b3 = rnd(M, 200), torch.zeros((640, 200), device="cuda"), torch.zeros(640, device="cuda")
+        w3t[:625], b3[:625] = rnd(625, 200), rnd(625)
+        out = torch.full((M, 640), float("nan"), device="cuda")
+        A.gemm_rows(x, w3t, out, w_transposed=True, bias=b3)
+        assert _rel(out[:, :625], x.double() @ w3t[:625].double().t() + b3[:625].double()) < 1e-5
+        assert float(out[:, 625:].abs().max()) == 0.0
+    with pytest.raises(A.UavAgentError):
+        A.gemm_rows(x, rnd(200, 640), out)                                 # x @ W with W [K, N]: N > 208 is not built
 
 
 # (M, I, J, ldb): J <= 208 runs plan 13, wider plan 20; ldb > J = a column slice of a padded buffer (the learner's logits: 625 of 640)
@@ -313,15 +337,17 @@ def test_update_with_hip_gemms_matches_the_update_with_torch_gemms():
     through torch.mm + separate relu6-backward passes: every gradient within float32 summation-order noise, and the HIP form is
     bit-reproducible."""
     torch = _torch()
-    r1, r2 = _twin_runners(torch, 700, 5, first=dict(hip_gemms=True, collect_launch="eager"), second=dict(hip_gemms=False, collect_launch="eager"))
-    assert r1.hip_gemms and not r2.hip_gemms
-    for it in range(2):
+    r1, r2 = _twin_runners(torch, 700, 5, first=dict(collect_launch="eager"), second=dict(collect_launch="eager"))
+    assert r1.hip_gemms and r2.hip_gemms               # (the twins collect with the same kernels: identical samples; only r2's UPDATE
+    for it in range(2):                                #  runs on torch GEMMs)
         b1, b2 = r1.collect(), r2.collect()
         for x, y in zip(b1, b2):
             assert torch.equal(x, y)
         if it == 1:
             r1._fwd_valid = r2._fwd_valid = False      # round 2: both recompute the forward pass (the HIP form with its own GEMM)
+        r2.hip_gemms = False
         s1, s2 = r1.update(*b1), r2.update(*b2)
+        r2.hip_gemms = True
         assert s1["hip_gemms"] and not s2["hip_gemms"]
         np.testing.assert_allclose([s1["a_loss"], s1["c_loss"]], [s2["a_loss"], s2["c_loss"]], rtol=1e-5)
         for k in r1.flat.gv:
