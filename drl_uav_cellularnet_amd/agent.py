@@ -307,7 +307,8 @@ class A2CRunner:
     around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
-                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True):
+                 update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
+                 overlap_allreduce=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -331,6 +332,10 @@ class A2CRunner:
         # hip_gemms: the update's dense layers through libuavagent's float32 MFMA kernels (csrc/agent_gemm.hip: relu6 masks and bias
         # gradients fused) instead of torch.mm + separate relu6-backward passes.  They are written for the reference's layer widths.
         self.hip_gemms = bool(hip_gemms) and HIDDEN == 200 and self.net.n_action <= 640
+        # more than one rank: the critic trunk's gradient (40 MB, first half of the exchange) is all-reduced on a side stream while the
+        # actor trunk's backward pass still runs (update_fused, hip_gemms path)
+        self.overlap_allreduce = bool(overlap_allreduce)
+        self._side = None
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
         # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
@@ -506,6 +511,25 @@ class A2CRunner:
             dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM)
         return self.flat.n_real, 1.0 / dist.get_world_size()
 
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _allreduce_bucket(self, lo, hi, async_op=False):
+        """Sum of flat.g[lo:hi] over ranks, in place.  nccl (RCCL): returns the work handle when async_op; gloo with CUDA tensors (the
+        one-GPU rehearsal: several ranks share the card, RCCL refuses that): through the host, synchronously."""
+        import torch.distributed as dist
+
+        buf = self.flat.g[lo:hi]
+        if buf.is_cuda and dist.get_backend() == "gloo":
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
+
     def _ensure_update_buffers(self, M, K):
         from . import _agent_capi as A
 
@@ -530,6 +554,8 @@ class A2CRunner:
             self._upd.update({"w3p": torch.zeros((H, ldl), dtype=torch.float32, device=dev),       # a_w3 in rows of ldl, zero tail
                               "ws_tn_h": A.gemm_tn_workspace(M, H, dev), "ws_tn_a": A.gemm_tn_workspace(M, NA, dev),
                               "ws_cs": A.gemm_rows_workspace(M, dev)})
+            if self._world() > 1 and self.overlap_allreduce:     # one table gradient per trunk: each needs its g rows contiguous
+                self._upd.update({"g_a": f(M, H), "g_c": f(M, H)})
         return self._upd
 
     @torch.no_grad()
@@ -569,7 +595,37 @@ class A2CRunner:
         # loss and its gradient w.r.t. logits / v (logits are overwritten); d a_b3, d c_b3
         A.a2c_loss_grad(b["logits"], b["v"], target, act, self.beta, b["dv"], gv["a_b3"], b["loss"], b["ws_loss"])
         gv["c_b3"].copy_(b["loss"][2:3].to(torch.float32))
-        if hip:
+        overlap = hip and ("g_a" in b)
+        ae = fl.actor_end
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        e_c0 = e_c1 = None
+        work_c = None
+        if overlap:
+            # ---- more than one rank: critic trunk first, its half of the gradient on the wire while the actor trunk runs ----
+            A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
+            A.gemm_tn(b["h1c"], b["dh"], gv["c_w2"], b["ws_tn_h"])
+            A.gemm_rows(b["dh"], net.c_w2, b["g_c"], w_transposed=True, relu6_mask_h=b["h1c"], colsum_out=gv["c_b1"], workspace=b["ws_cs"])
+            A.rows_grad(idx, b["g_c"], H, net.n_state, gv["c_w1"], None, b["ws_rows"])
+            main = torch.cuda.current_stream(self.dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            e_c0, e_c1 = ev(), ev()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                e_c0.record(self._side)
+                work_c = self._allreduce_bucket(ae, fl.n_flat, async_op=True)
+                if work_c is not None:
+                    work_c.wait()                                  # (the SIDE stream waits; the main stream goes on with the actor)
+                e_c1.record(self._side)
+            b["w3p"][:, :net.n_action].copy_(net.a_w3)
+            A.gemm_tn(b["h2a"], b["logits"], gv["a_w3"], b["ws_tn_a"])
+            A.gemm_rows(b["logits_pad"], b["w3p"], b["dh"], w_transposed=True, relu6_mask_h=b["h2a"])
+            A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
+            A.gemm_rows(b["dh"], net.a_w2, b["g_a"], w_transposed=True, relu6_mask_h=b["h1a"], colsum_out=gv["a_b1"], workspace=b["ws_cs"])
+            A.rows_grad(idx, b["g_a"], H, net.n_state, gv["a_w1"], None, b["ws_rows"])
+        elif hip:
             # actor trunk backwards: dW3; dh2a = relu6'(h2a) * (dlogits @ W3^T); dW2 + db2; dh1a = relu6'(h1a) * (dh2a @ W2^T) + db1
             b["w3p"][:, :net.n_action].copy_(net.a_w3)
             A.gemm_tn(b["h2a"], b["logits"], gv["a_w3"], b["ws_tn_a"])
@@ -595,20 +651,28 @@ class A2CRunner:
             torch.mm(b["h1c"].t(), b["dh"], out=gv["c_w2"])
             torch.mm(b["dh"], net.c_w2.t(), out=b["h2c"])
             A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
-        # first-layer tables: both in one sorted pass
-        A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
+        # first-layer tables: both in one sorted pass (one rank, or no overlap)
+        if not overlap:
+            A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
         # synchronise and step
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = ev(), ev()
         ev0.record()
-        n_red, g_scale = self._allreduce()
+        if overlap:
+            self._allreduce_bucket(0, ae)                              # the actor's half, behind its backward pass
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)     # ... and the critic's half has landed
+            n_red, g_scale = fl.n_real, 1.0 / self._world()
+        else:
+            n_red, g_scale = self._allreduce()
         ev1.record()
-        ae = fl.actor_end
         A.rmsprop_tf1(fl.w[:ae], fl.ms[:ae], fl.g[:ae], self.lr_a, g_scale=g_scale)
         A.rmsprop_tf1(fl.w[ae:], fl.ms[ae:], fl.g[ae:], self.lr_c, g_scale=g_scale)
         loss = b["loss"].cpu()                                        # (synchronises)
         self.stats = {"a_loss": float(loss[0]), "c_loss": float(loss[1]), "mean_reward": float(rew_buf.mean()),
                       "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1),
-                      "forward_reused": bool(reuse), "hip_gemms": bool(hip)}
+                      "forward_reused": bool(reuse), "hip_gemms": bool(hip),
+                      # two buckets (critic trunk, then actor trunk): the first one's time is hidden behind the actor's backward pass
+                      "allreduce_overlapped_ms": e_c0.elapsed_time(e_c1) if overlap else None,
+                      "allreduce_buckets": [4 * (fl.n_flat - ae), 4 * ae] if overlap else None}
         return self.stats
 
     def update_reference(self, idx_buf, act_buf, rew_buf, boot):

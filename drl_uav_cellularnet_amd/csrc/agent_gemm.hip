@@ -1082,7 +1082,7 @@ extern "C" int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_ro
 
 extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
     if (m_rows < 1) return 0;
-    size_t b = (size_t)((m_rows + 63) / 64) * kNP * sizeof(float);          // one partial row per workgroup of the 64-row kernel (the most)
+    size_t b = (size_t)((m_rows + 63) / 64) * kNP * sizeof(float);          // one partial row per workgroup of the 64-row kernels (the most)
 #ifdef UAVGEMM_STAMPS
     b += (size_t)((m_rows + 63) / 64) * 4 * 6 * sizeof(unsigned long long);
 #endif
@@ -1139,18 +1139,18 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
         else if (epi == 1) hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 1>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
         else hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 2>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
     } while (0)
-    static const int no_glds = [] { const char *e = std::getenv("UAVGEMM_NO_GLDS"); return e ? std::atoi(e) : 0; }();   // experiments only
-    if (w_transposed && vec && (k % kGlBK == 0) && !no_glds) {
+    if (w_transposed && vec && (k % kGlBK == 0)) {
         // LDS-DMA ring (gemm_rows_glds_kernel).  Few rows (a rollout step): 64-row workgroups, N in slices; many rows: 128-row workgroups.
-        if (m_rows <= 32768) { if (n <= 224) UAV_GL(64, 7, 3); else UAV_GL(64, 10, 3); }
+        // (64-row workgroups with a 2-stage ring: two of them fit a CU's LDS and cover each other's prologue / epilogue; measured at 8192
+        //  rows against a 3-stage ring with one workgroup per CU: 12.3 vs 13.3 us at N = 200, 26.2 vs 31.2 us at N = 640)
+        if (m_rows <= 32768) { if (n <= 224) UAV_GL(64, 7, 2); else UAV_GL(64, 10, 2); }
         else if (n <= 208) UAV_GL(128, 13, 2);
         else UAV_GL(128, 10, 2);
     } else if (w_transposed && vec) {
         // k-contiguous tiles, wide fragment reads (gemm_rows_nt_kernel).  Few rows (a rollout step): 64-row workgroups and N in slices,
         // so that 8192 rows still give >= 256 workgroups; many rows (the update): 128-row workgroups over all <= 208 columns.
-        static const int force_bm = [] { const char *e = std::getenv("UAVGEMM_BM"); return e ? std::atoi(e) : 0; }();   // experiments only
         if (m_rows <= 32768) { if (n <= 224) UAV_NT(64, 7); else UAV_NT(64, 10); }
-        else if (n <= 208) { if (force_bm == 64) UAV_NT(64, 13); else UAV_NT(128, 13); }
+        else if (n <= 208) UAV_NT(128, 13);
         else UAV_NT(128, 10);
     } else if (w_transposed) UAV_ROWS_E(true);
     else UAV_ROWS_E(false);
@@ -1159,8 +1159,7 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
 #undef UAV_ROWS_E
 #undef UAV_ARGS
     if (colp) {
-        static const int force_bm2 = [] { const char *e = std::getenv("UAVGEMM_BM"); return e ? std::atoi(e) : 0; }();
-        const long long n_part = (w_transposed && (m_rows <= 32768 || force_bm2 == 64)) ? (m_rows + 63) / 64 : (long long)grid.x;     // workgroups along M of the kernel that ran
+        const long long n_part = (w_transposed && m_rows <= 32768) ? (m_rows + 63) / 64 : (long long)grid.x;     // workgroups along M of the kernel that ran
         hipLaunchKernelGGL(rows_colsum_reduce, dim3((n + 63) / 64), dim3(1024), 0, st, colp, n_part, (int)n, colsum_out);
     }
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: launch failed");
