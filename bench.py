@@ -295,6 +295,8 @@ class EnvRun:
         import torch
 
         for n in sorted(set(sizes)):
+            if self.launch in ("many", "manypk"):
+                self.env.prepare_step_many(n)      # (the launch schedule of this segment length: built here, not inside the timed call)
             if self.launch == "graph" and n not in self.graphs:
                 self.graphs[n] = self.env.capture_steps(self.tape[:n])
             if self.launch == "many" and n not in self.many_out:

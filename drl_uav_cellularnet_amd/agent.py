@@ -358,7 +358,7 @@ class A2CRunner:
             # the actor's dense layers handed to uavagent_gemm_rows_f32 in its fast form: W^T (k-contiguous rows), the policy head
             # padded to LDL rows / bias entries of zeros (so the tail of every logits row comes out zero); refreshed from the
             # parameters at the start of every collect()
-            self._wt = {"a_w2t": f(H, H), "a_w3t": torch.zeros((self._ldl, H), dtype=torch.float32, device=self.dev),
+            self._wt = {"a_w2t": f(H, H), "c_w2t": f(H, H), "a_w3t": torch.zeros((self._ldl, H), dtype=torch.float32, device=self.dev),
                         "a_b3p": torch.zeros(self._ldl, dtype=torch.float32, device=self.dev)} if self.hip_gemms else None
         self._fwd_valid = False
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
@@ -405,8 +405,11 @@ class A2CRunner:
         wt = self._wt if cuda else None
         for t in range(T):
             if cuda:
+                # both trunks' first layers in one gather (tried twice, round 2 and round 3: the critic's half on a second stream beside
+                # the actor's GEMMs is SLOWER, 6.3-6.4 against 5.5 ms per rollout: two 800-byte gathers cost more than one of 1600)
                 A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
                                   out_c=fw["h1c"][t])
+            if cuda:
                 if wt is not None:       # float32 MFMA kernels, bias / relu6 fused, 64-row workgroups (8192 rows fill the chip)
                     A.gemm_rows(fw["h1a"][t], wt["a_w2t"], fw["h2a"][t], w_transposed=True, bias=net.a_b2, relu6=True)
                     A.gemm_rows(fw["h2a"][t], wt["a_w3t"], self._logits_pad[t], w_transposed=True, bias=wt["a_b3p"])
@@ -461,6 +464,7 @@ class A2CRunner:
         if wt is not None:
             net = self.net
             wt["a_w2t"].copy_(net.a_w2.t())
+            wt["c_w2t"].copy_(net.c_w2.t())
             wt["a_w3t"][:net.n_action].copy_(net.a_w3.t())
             wt["a_b3p"][:net.n_action].copy_(net.a_b3)
 
@@ -588,7 +592,10 @@ class A2CRunner:
                 torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
         self._fwd_valid = False                                        # the backward pass below overwrites logits and h2a
         if hip:
-            A.gemm_rows(b["h1c"], net.c_w2, b["h2c"], bias=net.c_b2, relu6=True)
+            if reuse:                                  # (collect() refreshed the transposed copies from these very weights)
+                A.gemm_rows(b["h1c"], self._wt["c_w2t"], b["h2c"], w_transposed=True, bias=net.c_b2, relu6=True)
+            else:
+                A.gemm_rows(b["h1c"], net.c_w2, b["h2c"], bias=net.c_b2, relu6=True)
         else:
             torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
         A.rowdot(b["h2c"], net.c_w3, net.c_b3, b["v"])

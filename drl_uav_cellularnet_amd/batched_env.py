@@ -303,6 +303,11 @@ class BatchedMobiEnv:
         st.walker_dev, st.bs_xy_dev, st.env_dev = packed["walker"].data_ptr(), packed["bs_xy"].data_ptr(), packed["env"].data_ptr()
         return st
 
+    def prepare_step_many(self, n_steps):
+        """Build whatever a step_many / step_many_packed call of ``n_steps`` steps needs ahead of time (the launch schedule of the
+        4096-env batch, uavenv_step_many_prepare): the first call with a new n_steps would otherwise build it, synchronously."""
+        _capi.check(self._lib.uavenv_step_many_prepare(self._h, int(n_steps)))
+
     def step_many_packed(self, actions, out=None):
         """step_many with one RECORD per walker / env and step instead of nine arrays (uavenv_step_many_packed): returns
         {"walker": uint8 [T, N, U, 12], "bs_xy": int32 [T, N, B, 2], "env": uint8 [T, N, 16]} (record layouts: WALKER_OUT_DTYPE,

@@ -525,7 +525,10 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
 // Returns the cached / newly built plan, or nullptr when rotation does not apply (then the plain launch runs).
 static long long rot_padded_slots(long long S) { return (S + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock; }
 static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
-    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < (h->rotate == 1 ? 2 : 8)) return nullptr;
+    // Automatic use from 48 steps per call on: each of the D ~ 4 launches of a schedule costs the ~8 us of load / store / launch phases a
+    // launch has, against ~0.6 us gained per step (4.31 T + 8 us plain, 3.70 T + 8 D us rotated: break-even near T = 39; a 20-step call
+    // measured 5.8e8 env-steps/s rotated against 6.7e8 plain, profiles/r03r_*).
+    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < (h->rotate == 1 ? 2 : 48)) return nullptr;
     const long long W = (h->N + h->kp.epw - 1) / h->kp.epw, S = h->rot_slots;
     if (W <= S || W >= 2 * S) return nullptr;
     for (const auto &pl : *h->rot_plans) if (pl.n_steps == T) return pl.dev ? &pl : nullptr;
@@ -600,6 +603,13 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
     if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }
     return remember((int)D, dev);
+}
+
+extern "C" int uavenv_step_many_prepare(uavenv_t *h, int n_steps) {
+    if (!h || n_steps < 0) return fail(UAVENV_E_INVALID, "step_many_prepare: null handle or negative n_steps");
+    DeviceGuard guard(h->device);
+    (void)rotation_plan(h, n_steps);      // builds + uploads + caches the schedule when one applies
+    return UAVENV_OK;
 }
 
 // Test hook: the schedule uavenv_step_many would use for n_steps (0 launches = plain launch).

@@ -24,7 +24,8 @@ extern "C" {
 #endif
 
 #define UAVENV_ABI_VERSION 4   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
-                                * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info */
+                                * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
+                                *      uavenv_step_many_prepare */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -199,6 +200,11 @@ int uavenv_lean_math_eval(int op, const double *a_dev, const double *b_dev, doub
 int uavenv_debug_variant_count(void);
 int uavenv_debug_variant_info(int i, char *name, size_t name_len, int *selectable, long long *launches);
 void uavenv_debug_variant_reset(void);
+
+/* Optional: prepare a multi-step call of n_steps ahead of time.  The first uavenv_step_many / _packed call with a new n_steps may build and
+ * upload a launch schedule (a few hundred microseconds of host time, synchronous); a caller that times the call (bench.py) or must not
+ * stall in it builds the schedule here instead.  Idempotent; 0 when there is nothing to prepare for this handle / n_steps. */
+int uavenv_step_many_prepare(uavenv_t *h, int n_steps);
 
 /* Test hook: how uavenv_step_many / uavenv_step_many_packed would run n_steps on this handle: *n_launches = 0 for the plain single
  * launch, else the number of launches of the rotation schedule and *slots wavefronts per launch.  Environment,

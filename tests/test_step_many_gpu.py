@@ -140,7 +140,7 @@ def test_rotation_is_automatic_at_the_baseline_batch_and_off_elsewhere():
 
     n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     nl, sl = C.c_int(-1), C.c_longlong(-1)
-    for n, T, expect in ((4096, 100, True), (4096, 20, True), (3072, 100, False), (6144, 100, False), (8192, 100, False), (4096, 4, False)):
+    for n, T, expect in ((4096, 100, True), (4096, 48, True), (4096, 20, False), (3072, 100, False), (6144, 100, False), (8192, 100, False), (4096, 4, False)):
         env = _env(n, 4, 20)
         assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
         waves = (n + 2) // 3

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""A/B of rollout-collection variants at BASELINE config 3 (8192 envs x 50 steps), interleaved in one process: ms per collect()."""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from drl_uav_cellularnet_amd import BatchedMobiEnv
+from drl_uav_cellularnet_amd.agent import A2CRunner
+variants = {"fused_gather": {}, "critic_side_stream": {"critic_side_stream": True}, "torch_gemms": {"hip_gemms": False}}
+runners = {}
+for k, kw in variants.items():
+    env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+    runners[k] = A2CRunner(env, rollout=50, **kw)
+    runners[k].collect(); runners[k].collect()
+res = {k: [] for k in variants}
+for rnd in range(4):
+    for k, r in runners.items():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            r.collect()
+        torch.cuda.synchronize(); res[k].append(round((time.perf_counter() - t0) / 5 * 1e3, 3))
+print(json.dumps(res))

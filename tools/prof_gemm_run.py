@@ -18,12 +18,13 @@ out = torch.empty(M, H, device=dev)
 gw2, gw3, gb2, gb3 = torch.empty(H, H, device=dev), torch.empty(H, NA, device=dev), torch.empty(H, device=dev), torch.empty(NA, device=dev)
 ws200, ws625 = A.gemm_tn_workspace(M, H, dev), A.gemm_tn_workspace(M, NA, dev)
 reps = int(os.environ.get("REPS", "5"))
+wscs = A.gemm_rows_workspace(M, dev)
+w2t = w2.t().contiguous()
 for _ in range(reps):
-    A.gemm_rows(x, w2, out, bias=b2, relu6=True)
-    A.gemm_rows(y, w2, out, w_transposed=True)
-    A.gemm_rows(y, w2, out, w_transposed=True, relu6_mask_h=h)
-    A.gemm_rows(dl, w3p, out, w_transposed=True)
-    A.gemm_tn(x, y, gw2, ws200, dbias_out=gb2)
-    A.gemm_tn(x, dl[:, :NA], gw3, ws625, dbias_out=gb3)
+    A.gemm_rows(x, w2t, out, w_transposed=True, bias=b2, relu6=True)                                   # critic layer 2 forwards
+    A.gemm_rows(y, w2, out, w_transposed=True, relu6_mask_h=h, colsum_out=gb2, workspace=wscs)         # dX through a 200-wide layer
+    A.gemm_rows(dl, w3p, out, w_transposed=True, relu6_mask_h=h)                                       # dX through the policy head
+    A.gemm_tn(x, y, gw2, ws200, dbias_out=gb2)                                                         # dW 200 x 200
+    A.gemm_tn(x, dl[:, :NA], gw3, ws625, dbias_out=gb3)                                                # dW 200 x 625
 torch.cuda.synchronize()
 print("ok")
