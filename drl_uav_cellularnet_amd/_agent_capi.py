@@ -15,7 +15,8 @@ EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_
            "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
            "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
-           "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32")
+           "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32",
+           "uavagent_debug_tn_plan_check")
 ABI_VERSION = 3
 
 _lib = None
@@ -67,6 +68,8 @@ def load():
     lib.uavagent_rows_grad_workspace_bytes.argtypes = [_I64, _I32, _I32, _I64]
     lib.uavagent_gemm_tn_workspace_bytes.restype = C.c_size_t
     lib.uavagent_gemm_tn_workspace_bytes.argtypes = [_I64, _I32]
+    lib.uavagent_debug_tn_plan_check.restype = C.c_int
+    lib.uavagent_debug_tn_plan_check.argtypes = [_I32]
     lib.uavagent_gemm_rows_workspace_bytes.restype = C.c_size_t
     lib.uavagent_gemm_rows_workspace_bytes.argtypes = [_I64]
     if lib.uavagent_abi_version() != ABI_VERSION:

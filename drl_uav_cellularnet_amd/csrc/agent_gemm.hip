@@ -1044,6 +1044,37 @@ TnShape tn_shape(long long M, int n_j) {
 }
 }  // namespace
 
+namespace {
+template <int PLAN> int tn_plan_check() {
+    using P = TnPlan<PLAN>;
+    int owners[kRB][P::NCB] = {};
+    for (int w = 0; w < 8; ++w) {
+        for (int blk = 0; blk < P::NR * P::NC; ++blk) {
+            const int rb = P::r0(w) + blk / P::NC, cb = P::c0(w) + blk % P::NC;
+            if (rb < 0 || rb >= kRB || cb < 0 || cb >= P::NCB) return -1;
+            ++owners[rb][cb];
+        }
+        for (int i = 0; i < P::NX; ++i) {
+            const int rb = P::xr(w, i), cb = P::xc(w, i);
+            if (rb < 0 || rb >= kRB || cb < 0 || cb >= P::NCB) return -2;     // (duplicates too must read inside the tile)
+            if (P::xvalid(w, i)) ++owners[rb][cb];
+        }
+    }
+    for (int rb = 0; rb < kRB; ++rb)
+        for (int cb = 0; cb < P::NCB; ++cb)
+            if (owners[rb][cb] != 1) return -3;
+    return 8 * P::NBLKW;                                                     // MFMAs issued per k-step and workgroup
+}
+}  // namespace
+
+// Test hook (host only, no GPU): every 16 x 16 output block of a dW tile is owned by exactly one wavefront of the plan; returns the
+// number of MFMAs a workgroup issues per k-step (176 for 169 real blocks of plan 13, 264 for 260 of plan 20), negative on a hole / overlap.
+extern "C" int uavagent_debug_tn_plan_check(int32_t plan) {
+    if (plan == 13) return tn_plan_check<13>();
+    if (plan == 20) return tn_plan_check<20>();
+    return fail3(UAVAGENT_E_INVALID, "tn_plan_check: plans 13 and 20 exist");
+}
+
 extern "C" size_t uavagent_gemm_tn_workspace_bytes(int64_t m_rows, int32_t n_j) {
     if (m_rows < 0 || n_j < 1) return 0;
     return tn_shape(m_rows, n_j).ws_bytes;

@@ -121,6 +121,9 @@ int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t 
  * sums go to `workspace` (16-byte aligned, uavagent_gemm_tn_workspace_bytes(m_rows, n_j) bytes) and a second pass adds them in a fixed
  * order: bit-reproducible, no float atomics. */
 size_t uavagent_gemm_tn_workspace_bytes(int64_t m_rows, int32_t n_j);
+/* Test hook (host only): the dW kernel deals the 13 x 13 (plan 13) or 13 x 20 (plan 20) output blocks of a tile out to 8 wavefronts of equal
+ * shape; > 0 = MFMAs issued per k-step when every block has exactly one owner, negative on a hole or an overlap. */
+int uavagent_debug_tn_plan_check(int32_t plan);
 int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_rows, int32_t n_i, int32_t n_j, int64_t ldb, float *c, int64_t ldc,
                          float *dbias_out, void *workspace, size_t workspace_bytes, void *stream);
 

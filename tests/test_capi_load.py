@@ -59,6 +59,29 @@ def test_agent_library_exports_its_header():
     assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 0, 24, 200, 100, None) == 0   # m_rows = 0: no launch
 
 
+def test_gemm_host_logic_without_gpu():
+    """The learner's GEMM entry points (ABI 3): argument checks answer before any HIP call, workspace sizes, and the balanced block plans of
+    the dW kernel (every 16 x 16 block of a tile owned by exactly one wavefront)."""
+    from drl_uav_cellularnet_amd import _agent_capi
+
+    lib = _agent_capi.load()
+    assert lib.uavagent_debug_tn_plan_check(13) == 8 * 22          # 169 real blocks of 176 issued
+    assert lib.uavagent_debug_tn_plan_check(20) == 8 * 33          # 260 of 264
+    assert lib.uavagent_debug_tn_plan_check(7) == -1
+    one = ctypes.c_void_p(16)
+    # one slab per workgroup: 256 splits x 8 waves x 22 blocks x 64 lanes x 16 B at the update's size; two J tiles x 128 splits x 33 blocks for 625
+    assert lib.uavagent_gemm_tn_workspace_bytes(409600, 200) == 256 * 8 * 22 * 64 * 16
+    assert lib.uavagent_gemm_tn_workspace_bytes(409600, 625) == 256 * 8 * 33 * 64 * 16
+    assert lib.uavagent_gemm_rows_workspace_bytes(409600) == 6400 * 208 * 4
+    assert lib.uavagent_gemm_tn_f32(one, one, 1000, 202, 200, 200, one, 200, None, one, 1 << 30, None) == -1     # n_i % 4
+    assert lib.uavagent_gemm_tn_f32(one, one, 1000, 200, 200, 200, one, 200, None, one, 16, None) == -1          # workspace too small
+    assert b"workspace" in lib.uavagent_last_error()
+    assert lib.uavagent_gemm_rows_f32(one, 200, one, 200, 1, 1000, 200, 2000, None, 0, None, 0, one, 2000, None, None, 0, None) == -1   # n > 1024
+    assert lib.uavagent_gemm_rows_f32(one, 200, one, 640, 0, 1000, 200, 640, None, 0, None, 0, one, 640, None, None, 0, None) == -1    # x @ W, N > 208
+    assert b"w_transposed" in lib.uavagent_last_error()
+    assert lib.uavagent_gemm_rows_f32(one, 200, one, 200, 1, 1000, 200, 200, one, 1, one, 200, one, 200, None, None, 0, None) == -1    # mask + bias
+
+
 def test_host_side_calls_without_gpu():
     from drl_uav_cellularnet_amd import _capi
 
