@@ -16,7 +16,7 @@ EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
            "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
            "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32",
-           "uavagent_debug_tn_plan_check")
+           "uavagent_debug_tn_plan_check", "uavagent_actor_head_f32")
 ABI_VERSION = 3
 
 _lib = None
@@ -55,6 +55,7 @@ def load():
         "uavagent_rmsprop_tf1": [_P, _P, _P, _I64, _F, _F, _F, _F, _P],
         "uavagent_gemm_rows_f32": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
         "uavagent_gemm_tn_f32": [_P, _P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
+        "uavagent_actor_head_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I64, _P, _P],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -267,6 +268,22 @@ def gemm_rows(a, w, out, w_transposed=False, bias=None, relu6=False, relu6_mask_
                                       _ptr(out), _row_stride(out, "out"), _ptr(colsum_out), _ptr(workspace),
                                       0 if workspace is None else workspace.numel(), _stream(a.device)), "uavagent_gemm_rows_f32")
     return out
+
+
+def actor_head(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2_out, logits_pad_out, actions_out):
+    """h2 = relu6(h1 @ W2 + b2); logits = h2 @ W3 + b3; one action per row by the inverse-CDF draw: uavagent_actor_head_f32 (one launch;
+    bit-identical to gemm_rows x 2 + sample_actions).  logits_pad_out: [N, >= 640] rows, all 640 columns written (zero tail)."""
+    for t, what in ((h1, "h1"), (w2t, "w2t"), (b2, "b2"), (w3t_padded, "w3t_padded"), (b3_padded, "b3_padded"), (uniforms, "uniforms"), (h2_out, "h2_out")):
+        _f32c(t, what)
+    N, H = h1.shape
+    if tuple(w2t.shape) != (H, H) or w3t_padded.shape[1] != H or w3t_padded.shape[0] != b3_padded.numel() or tuple(h2_out.shape) != (N, H):
+        raise UavAgentError("actor_head: shapes do not agree")
+    if actions_out.dtype != torch.int64 or actions_out.numel() != N or uniforms.numel() != N or logits_pad_out.shape[0] != N:
+        raise UavAgentError("actor_head: one uniform, one logits row and one int64 action per row of h1")
+    _check(load().uavagent_actor_head_f32(_ptr(h1), _ptr(w2t), _ptr(b2), _ptr(w3t_padded), _ptr(b3_padded), _ptr(uniforms), N, H, int(n_actions),
+                                          _ptr(h2_out), _ptr(logits_pad_out), _row_stride(logits_pad_out, "logits_pad_out"), _ptr(actions_out),
+                                          _stream(h1.device)), "uavagent_actor_head_f32")
+    return actions_out
 
 
 def gemm_tn_workspace(m_rows, n_j, device):

@@ -308,7 +308,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True):
+                 overlap_allreduce=True, fused_head=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -335,6 +335,8 @@ class A2CRunner:
         # more than one rank: the critic trunk's gradient (40 MB, first half of the exchange) is all-reduced on a side stream while the
         # actor trunk's backward pass still runs (update_fused, hip_gemms path)
         self.overlap_allreduce = bool(overlap_allreduce)
+        # fused_head: layer 2, the policy head and the action draw of a rollout step as ONE kernel (uavagent_actor_head_f32)
+        self.fused_head = bool(fused_head) and self.hip_gemms and 576 < self.net.n_action <= 640
         self._side = None
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
@@ -410,13 +412,17 @@ class A2CRunner:
                 A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
                                   out_c=fw["h1c"][t])
             if cuda:
-                if wt is not None:       # float32 MFMA kernels, bias / relu6 fused, 64-row workgroups (8192 rows fill the chip)
+                if wt is not None and self.fused_head:      # layer 2 + policy head + action draw: one launch, 32 rows per workgroup
+                    A.actor_head(fw["h1a"][t], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf[t], net.n_action,
+                                 fw["h2a"][t], self._logits_pad[t], self.act_buf[t])
+                elif wt is not None:     # float32 MFMA kernels, bias / relu6 fused, 64-row workgroups (8192 rows fill the chip)
                     A.gemm_rows(fw["h1a"][t], wt["a_w2t"], fw["h2a"][t], w_transposed=True, bias=net.a_b2, relu6=True)
                     A.gemm_rows(fw["h2a"][t], wt["a_w3t"], self._logits_pad[t], w_transposed=True, bias=wt["a_b3p"])
+                    A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
                 else:
                     torch.addmm(net.a_b2, fw["h1a"][t], net.a_w2, out=fw["h2a"][t]).clamp_(0.0, 6.0)
                     torch.addmm(net.a_b3, fw["h2a"][t], net.a_w3, out=fw["logits"][t])
-                A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
+                    A.sample_actions(fw["logits"][t], self.u_buf[t], out=self.act_buf[t])
             else:
                 prob = net.actor_only(self.idx_buf[t])
                 self.act_buf[t] = sample_actions(prob, uniforms=self.u_buf[t])

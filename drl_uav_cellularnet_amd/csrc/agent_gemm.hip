@@ -915,6 +915,258 @@ __global__ __launch_bounds__(BM * 4) void gemm_rows_glds_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The actor's head of one rollout step in ONE kernel (choose_action, main.py:165-169 with the network of main.py:147-150):
+//   h2 = relu6(h1 @ W2 + b2);  logits = h2 @ W3 + b3;  action ~ softmax(logits) by the inverse-CDF draw of uavagent_sample_actions.
+// As three launches (two gemm_rows_glds launches + the sampling kernel) a step spends 12 + 26 + 9 us of which about a third is launch,
+// prologue (the first tiles' round trip), epilogue and the re-read of the logits; here a workgroup owns 32 rows from h1 to the action:
+// h1 tile -> LDS (DMA), W2^T streamed through a 2-stage LDS-DMA ring (5 chunks of 40 k), h2 tile kept in LDS (and stored for the update),
+// W3^T streamed through the same ring in two halves of 320 policy columns (10 chunks), all 640 logits of the 32 rows held in the
+// accumulators of the 4 waves, then written to an LDS tile from which the rows are stored (coalesced) and sampled.  Same k order per output
+// element as gemm_rows_glds_kernel, same arithmetic as sample_actions_kernel: results are bit-identical to the three-launch form.
+// 8 waves, two per SIMD: wave w = row block w & 1, column quarter w >> 1 (4 of 16 column blocks in layer 2 -- 13 are real --, 5 of 20 in each
+// policy half).  (With 4 waves each wave issued 13 LDS-DMA instructions per 100 MFMAs and a lone workgroup took 41 us.)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kHdRows = 32, kHdH = 200, kHdNP = 640, kHdWaves = 8, kHdThr = kHdWaves * 64;
+constexpr int kHdH1F4 = kHdRows * kHdH / 4, kHdH1Pass = (kHdH1F4 + kHdThr - 1) / kHdThr;         // 1600 float4: 4 passes (the last one: 1 wave)
+constexpr int kHdW2Rows = 256, kHdW2Pass = kHdW2Rows * 10 / kHdThr;                              // 2560 float4: 5 passes
+constexpr int kHdW3Rows = 320, kHdW3Pass = (kHdW3Rows * 10 + kHdThr - 1) / kHdThr;               // 3200 float4: 7 passes (the last one: 2 waves)
+constexpr int kHdStageF = kHdW3Rows * kGlBK;                                                    // 12 800 floats per ring stage
+constexpr int kHdLdsF = 2 * kHdRows * kHdH + 2 * kHdStageF;                                     // 38 400 floats = 153 600 B
+static_assert(kHdW2Rows * kGlBK <= kHdStageF && 2 * kHdStageF >= kHdRows * kHdNP && kHdH1F4 % 64 == 0 && (kHdW3Rows * 10) % 64 == 0, "the head's LDS plan");
+
+__device__ __forceinline__ float wave_max_g(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// 10 k-steps of one chunk: NCB column blocks of one 16-row block.  pa = this lane's A row at the chunk's first k, pw = its W row of
+// column block 0 in the stage (row stride 40); group g + 1 is read while the first k-step of group g issues (see gemm_rows_glds_kernel).
+template <int NCB>
+__device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int q, f32x4 (&acc)[NCB]) {
+    f32x4 a01[2], w01[2][NCB];
+    f32x2 a2, w2[NCB];
+    a01[0] = *reinterpret_cast<const f32x4 *>(pa + 4 * q);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) w01[0][cb] = *reinterpret_cast<const f32x4 *>(pw + cb * 16 * kGlBK + 4 * q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < kGlBK / 4; ++ks) {
+        const int g = ks >> 2, e = ks & 3;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (ks == 0) {
+                if (cb == 0) a01[1] = *reinterpret_cast<const f32x4 *>(pa + 16 + 4 * q);
+                w01[1][cb] = *reinterpret_cast<const f32x4 *>(pw + cb * 16 * kGlBK + 16 + 4 * q);
+            }
+            if (ks == 4) {
+                if (cb == 0) a2 = *reinterpret_cast<const f32x2 *>(pa + 32 + 2 * q);
+                w2[cb] = *reinterpret_cast<const f32x2 *>(pw + cb * 16 * kGlBK + 32 + 2 * q);
+            }
+            const float av = (g < 2) ? a01[g < 2 ? g : 0][e] : a2[e & 1];
+            const float wv = (g < 2) ? w01[g < 2 ? g : 0][cb][e] : w2[cb][e & 1];
+            acc[cb] = MFMA16(av, wv, acc[cb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                                const float *__restrict__ w3t, const float *__restrict__ b3p,
+                                                                const float *__restrict__ uni, long long n_rows, int n_act,
+                                                                float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
+                                                                long long *__restrict__ action) {
+    __shared__ __attribute__((aligned(16))) float lds[kHdLdsF];
+    float *const sH1 = lds, *const sH2 = lds + kHdRows * kHdH, *const ring = lds + 2 * kHdRows * kHdH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4, rb = wave & 1, qt = wave >> 1;          // row block, column quarter
+    const long long m0 = (long long)blockIdx.x * kHdRows;
+    using set0_t = std::integral_constant<int, 0>;
+    using set1_t = std::integral_constant<int, 1>;
+    // (every wait below is vmcnt(0), so the waves need not issue the same number of LDS-DMA instructions: passes are cut at whole waves)
+
+    // ---- phase 0: the h1 tile (32 x 200 contiguous floats) and chunk 0 of W2^T ----
+    {
+        const long long lim = (n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows) * (kHdH / 4);      // float4s of the tile that exist
+        const float *g0 = h1 + m0 * kHdH;
+#pragma unroll
+        for (int p = 0; p < kHdH1Pass; ++p) {
+            const int slot = p * kHdWaves + wave;
+            if (slot * 64 < kHdH1F4) {
+                const int idx = slot * 64 + lane;
+                const float *g = (idx < lim) ? g0 + idx * 4 : g_zero16;
+                __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sH1 + slot * 256), 16, 0, 0);
+            }
+        }
+    }
+    // W2^T [200, 200] as 256 tile rows (rows >= 200: zeros) x 40 k per chunk; two pointer sets (even / odd chunks), see gemm_rows_glds_kernel
+    const float *s2[2][kHdW2Pass];
+    unsigned real2 = 0u;
+#pragma unroll
+    for (int p = 0; p < kHdW2Pass; ++p) {
+        const int idx = (p * kHdWaves + wave) * 64 + lane, row = idx / 10, c4 = idx - row * 10;
+        const float *g = g_zero16;
+        if (row < kHdH) { g = w2t + row * kHdH + c4 * 4; real2 |= 1u << p; }
+        s2[0][p] = g;
+        s2[1][p] = g + (((real2 >> p) & 1u) ? kGlBK : 0);
+    }
+    auto issue2 = [&](auto set_c, int c) {
+        constexpr int SET = decltype(set_c)::value;
+        float *stage = ring + (c & 1) * kHdStageF;
+#pragma unroll
+        for (int p = 0; p < kHdW2Pass; ++p) {
+            if (c >= 2) s2[SET][p] += (((real2 >> p) & 1u) ? 2 * kGlBK : 0);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)s2[SET][p], (lds_void_t *)(stage + (p * kHdWaves + wave) * 256), 16, 0, 0);
+        }
+    };
+    issue2(set0_t{}, 0);
+
+    // ---- phase 1: h2 = relu6(h1 @ W2 + b2): wave = 16 rows x 4 of 16 column blocks (13 real) ----
+    f32x4 acc1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *pa1 = sH1 + (rb * 16 + r) * kHdH;
+    auto chunk2 = [&](auto set_c, int c) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 5) issue2(set_c, c + 1);
+        head_chunk<4>(pa1 + c * kGlBK, ring + (c & 1) * kHdStageF + (qt * 4 * 16 + r) * kGlBK, q, acc1);
+    };
+    chunk2(set1_t{}, 0); chunk2(set0_t{}, 1); chunk2(set1_t{}, 2); chunk2(set0_t{}, 3); chunk2(set1_t{}, 4);
+    // bias + relu6 -> the h2 tile in LDS (row = m, k-contiguous: the A operand of the policy head)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = (qt * 4 + cb) * 16 + r;
+        if (col < kHdH) {
+            const float bv = b2[col];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sH2[(rb * 16 + 4 * q + t) * kHdH + col] = fminf(fmaxf(acc1[cb][t] + bv, 0.0f), 6.0f);
+        }
+    }
+    __syncthreads();                                   // (every wave is past the ring's last read too: phase 2 may refill it)
+
+    // ---- phase 2: logits = h2 @ W3 + b3, two halves of 320 policy columns x 5 chunks: wave = 16 rows x 5 of 20 column blocks ----
+    const float *s3[2][kHdW3Pass];
+#pragma unroll
+    for (int p = 0; p < kHdW3Pass; ++p) {
+        const int idx = (p * kHdWaves + wave) * 64 + lane, row = idx / 10, c4 = idx - row * 10;
+        const float *g = (row < kHdW3Rows) ? w3t + row * kHdH + c4 * 4 : g_zero16;     // (w3t has 640 rows: rows >= n_act are zeros)
+        s3[0][p] = g;
+        s3[1][p] = (row < kHdW3Rows) ? g + kGlBK : g;
+    }
+    // chunk index p3 = 0..9: half p3 / 5, k chunk p3 % 5; a set is advanced from chunk p to chunk p + 2
+    auto off3 = [](int p3) { return (p3 / 5) * (kHdW3Rows * kHdH) + (p3 % 5) * kGlBK; };
+    auto issue3 = [&](auto set_c, int p3) {
+        constexpr int SET = decltype(set_c)::value;
+        float *stage = ring + (p3 & 1) * kHdStageF;
+        const int delta = (p3 >= 2) ? off3(p3) - off3(p3 - 2) : 0;
+#pragma unroll
+        for (int p = 0; p < kHdW3Pass; ++p) {
+            const int slot = p * kHdWaves + wave;
+            if (slot * 64 < kHdW3Rows * 10) {
+                if (p3 >= 2) s3[SET][p] += delta;
+                __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)s3[SET][p], (lds_void_t *)(stage + slot * 256), 16, 0, 0);
+            }
+        }
+    };
+    issue3(set0_t{}, 0);
+    // store the h2 tile for the update while the first chunk is on its way: 1600 float4, coalesced rows
+    {
+        const long long lim = (n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows) * (kHdH / 4);
+#pragma unroll
+        for (int i = 0; i < kHdH1Pass; ++i) {
+            const int idx = tid + kHdThr * i;
+            if (idx < lim) *reinterpret_cast<float4 *>(h2_out + m0 * kHdH + idx * 4) = *reinterpret_cast<const float4 *>(sH2 + idx * 4);
+        }
+    }
+    f32x4 acc2[2][5];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc2[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *pa2 = sH2 + (rb * 16 + r) * kHdH;
+    auto chunk3 = [&](auto set_c, auto nh_c, int p3) {
+        constexpr int NH = decltype(nh_c)::value;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (p3 + 1 < 10) issue3(set_c, p3 + 1);
+        head_chunk<5>(pa2 + (p3 % 5) * kGlBK, ring + (p3 & 1) * kHdStageF + (qt * 5 * 16 + r) * kGlBK, q, acc2[NH]);
+    };
+    chunk3(set1_t{}, set0_t{}, 0); chunk3(set0_t{}, set0_t{}, 1); chunk3(set1_t{}, set0_t{}, 2); chunk3(set0_t{}, set0_t{}, 3); chunk3(set1_t{}, set0_t{}, 4);
+    chunk3(set0_t{}, set1_t{}, 5); chunk3(set1_t{}, set1_t{}, 6); chunk3(set0_t{}, set1_t{}, 7); chunk3(set1_t{}, set1_t{}, 8); chunk3(set0_t{}, set1_t{}, 9);
+    __syncthreads();                                   // the ring is free: it becomes the [32][640] logits tile
+
+    // ---- phase 3: + bias -> logits tile in LDS; coalesced store; one wave samples 4 rows ----
+    float *sL = ring;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int cb = 0; cb < 5; ++cb) {
+            const int col = nh * kHdW3Rows + (qt * 5 + cb) * 16 + r;
+            const float bv = b3p[col];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sL[(rb * 16 + 4 * q + t) * kHdNP + col] = acc2[nh][cb][t] + bv;
+        }
+    __syncthreads();
+    {
+        const int rows = (int)(n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows);
+#pragma unroll 5
+        for (int i = 0; i < kHdRows * kHdNP / 4 / kHdThr; ++i) {                  // 5120 float4 over 512 threads
+            const int idx = tid + kHdThr * i, row = idx / (kHdNP / 4), c4 = idx - row * (kHdNP / 4);
+            if (row < rows) *reinterpret_cast<float4 *>(logits + (m0 + row) * ldl + c4 * 4) = *reinterpret_cast<const float4 *>(sL + row * kHdNP + c4 * 4);
+        }
+    }
+    constexpr int PER = 10;                            // sample_actions_kernel<10>: lane l owns columns 10 l .. 10 l + 9
+    for (int i = 0; i < kHdRows / kHdWaves; ++i) {
+        const int lr = wave * (kHdRows / kHdWaves) + i;
+        const long long m = m0 + lr;
+        if (m >= n_rows) break;
+        const float *row = sL + lr * kHdNP;
+        float v[PER];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane * PER + k;
+            v[k] = (c < n_act) ? row[c] : -3.0e38f;
+            mx = fmaxf(mx, v[k]);
+        }
+        mx = wave_max_g(mx);
+        float loc = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane * PER + k;
+            v[k] = (c < n_act) ? expf(v[k] - mx) : 0.f;
+            loc += v[k];
+        }
+        float incl = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const float total = __shfl(incl, 63, 64);
+        const float target = uni[m] * total;
+        const unsigned long long over = __ballot(incl > target);
+        int a = n_act - 1;
+        if (over != 0ull) {
+            const int first = __ffsll((long long)over) - 1;
+            float c = __shfl(incl - loc, first, 64);
+            int found = -1;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                c += __shfl(v[k], first, 64);
+                if (found < 0 && c > target) found = first * PER + k;
+            }
+            a = found < 0 ? first * PER + PER - 1 : found;
+            if (a > n_act - 1) a = n_act - 1;
+        }
+        if (lane == 0) action[m] = a;
+    }
+}
+
 template <bool NT, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
                                                             int K, int N, long long M, const float *__restrict__ bias, int relu6,
@@ -1108,6 +1360,24 @@ extern "C" int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_ro
     if (s.plan == 13) UAV_TN(13); else UAV_TN(20);
 #undef UAV_TN
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_tn: launch failed");
+    return UAVAGENT_OK;
+}
+
+extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
+                                       const float *uniforms, int64_t n_rows, int32_t n_hidden, int32_t n_actions, float *h2_out,
+                                       float *logits_out, int64_t ld_logits, int64_t *actions_out, void *stream) {
+    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out)
+        return fail3(UAVAGENT_E_INVALID, "actor_head: null pointer");
+    if (n_hidden != kHdH || n_actions <= 576 || n_actions > kHdNP || ld_logits < kHdNP || (ld_logits & 3) || n_rows < 0)
+        return fail3(UAVAGENT_E_INVALID, "actor_head: built for 200 hidden units and 577..640 actions (the reference's 625 = 5^4; 10 policy columns "
+                                         "per lane, like uavagent_sample_actions at that width), ld_logits >= 640 and a multiple of 4");
+    if (!aligned16(h1) || !aligned16(w2t) || !aligned16(w3t_padded) || !aligned16(h2_out) || !aligned16(logits_out))
+        return fail3(UAVAGENT_E_INVALID, "actor_head: matrices must be 16-byte aligned");
+    if (n_rows == 0) return UAVAGENT_OK;
+    hipLaunchKernelGGL(actor_head_kernel, dim3((unsigned)((n_rows + kHdRows - 1) / kHdRows)), dim3(kHdThr), 0, (hipStream_t)stream, h1, w2t, b2, w3t_padded,
+                       b3_padded, uniforms, (long long)n_rows, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
+                       reinterpret_cast<long long *>(actions_out));
+    if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head: launch failed");
     return UAVAGENT_OK;
 }
 

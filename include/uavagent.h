@@ -115,6 +115,16 @@ int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t 
                            int32_t n, const float *bias, int32_t relu6, const float *relu6_mask_h, int64_t ldh, float *c, int64_t ldc,
                            float *colsum_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The actor's head of one rollout step in ONE launch (choose_action, main.py:165-169, on the network of main.py:147-150):
+ *   h2 = relu6(h1 @ W2 + b2);  logits = h2 @ W3 + b3;  actions_out[n] = the inverse-CDF draw of uavagent_sample_actions with uniforms[n].
+ * Bit-identical to uavagent_gemm_rows_f32 (twice) + uavagent_sample_actions.  Built for the reference's widths: n_hidden = 200 and
+ * 577..640 actions (625 = 5^4).  h1 f32 [n_rows, 200] contiguous; w2t f32 [200, 200] = W2 TRANSPOSED; b2 f32 [200]; w3t_padded f32
+ * [640, 200] = W3 transposed, rows >= n_actions zero; b3_padded f32 [640], entries >= n_actions zero; h2_out f32 [n_rows, 200];
+ * logits_out f32 [n_rows, 640 of ld_logits] (the tail comes out zero); actions_out int64 [n_rows].  16-byte aligned matrices. */
+int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
+                            const float *uniforms, int64_t n_rows, int32_t n_hidden, int32_t n_actions, float *h2_out, float *logits_out,
+                            int64_t ld_logits, int64_t *actions_out, void *stream);
+
 /* Weight gradient:  c[i, j] = sum_m a[m, i] * b[m, j]  and, when dbias_out != NULL, dbias_out[j] = sum_m b[m, j]  (the bias gradient of
  * the same layer: a column of ones rides along in the kernel).  a f32 [m_rows, n_i] CONTIGUOUS (n_i % 4 == 0, <= 200, 16-byte aligned),
  * b f32 [m_rows, n_j] (row stride ldb, n_j <= 640), c f32 [n_i, n_j] (row stride ldc).  The sum over m is split over the CUs; partial

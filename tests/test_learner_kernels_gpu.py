@@ -296,6 +296,37 @@ def test_gemm_rows_wide_output_in_slices():
         A.gemm_rows(x, rnd(200, 640), out)                                 # x @ W with W [K, N]: N > 208 is not built
 
 
+@pytest.mark.parametrize("n_rows", [8192, 33, 1000])
+def test_actor_head_kernel_equals_the_three_launches(n_rows):
+    """uavagent_actor_head_f32 (layer 2 + policy head + inverse-CDF draw in one kernel, a workgroup per 32 rows) against
+    uavagent_gemm_rows_f32 twice + uavagent_sample_actions: h2, logits (incl. the zero tail) and actions bit for bit, and against float64."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    g = torch.Generator(device="cuda").manual_seed(n_rows)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
+    H, NA = 200, 625
+    h1 = (rnd(n_rows, H) * 4.0 + 2.0).clamp_(0.0, 6.0)
+    w2, b2, w3, b3 = rnd(H, H) * 0.2, rnd(H), rnd(H, NA) * 0.3, rnd(NA)
+    w2t = w2.t().contiguous()
+    w3t, b3p = torch.zeros((640, H), device="cuda"), torch.zeros(640, device="cuda")
+    w3t[:NA], b3p[:NA] = w3.t(), b3
+    u = torch.rand(n_rows, device="cuda", generator=g)
+    u[0] = 0.0
+    h2a, lga, acta = torch.full((n_rows, H), float("nan"), device="cuda"), torch.full((n_rows, 640), float("nan"), device="cuda"), torch.full((n_rows,), -1, dtype=torch.int64, device="cuda")
+    h2b, lgb = torch.empty_like(h2a), torch.empty_like(lga)
+    A.actor_head(h1, w2t, b2, w3t, b3p, u, NA, h2a, lga, acta)
+    A.gemm_rows(h1, w2t, h2b, w_transposed=True, bias=b2, relu6=True)
+    A.gemm_rows(h2b, w3t, lgb, w_transposed=True, bias=b3p)
+    actb = A.sample_actions(lgb[:, :NA], u)
+    assert torch.equal(h2a, h2b) and torch.equal(lga, lgb) and torch.equal(acta, actb)
+    assert float(lga[:, NA:].abs().max()) == 0.0
+    want_h2 = (h1.double() @ w2.double() + b2.double()).clamp(0.0, 6.0)
+    assert _rel(h2a, want_h2) < 1e-5 and _rel(lga[:, :NA], want_h2 @ w3.double() + b3.double()) < 1e-5
+    with pytest.raises(A.UavAgentError):
+        A.actor_head(h1, w2t, b2, w3t, b3p, u, 100, h2a, lga, acta)          # built for the reference's 625 actions (577..640)
+
+
 # (M, I, J, ldb): J <= 208 runs plan 13, wider plan 20; ldb > J = a column slice of a padded buffer (the learner's logits: 625 of 640)
 TN_SHAPES = [(1, 200, 200, 200), (31, 200, 200, 200), (5000, 200, 200, 200), (40037, 200, 200, 200), (3000, 200, 625, 640), (2999, 200, 625, 625),
              (700, 200, 640, 640), (1500, 64, 100, 100), (900, 200, 321, 324), (1200, 8, 5, 5)]

@@ -27,5 +27,8 @@ res["gemm2_hip_us"] = timed(lambda: A.gemm_rows(x, w2t, h2, w_transposed=True, b
 res["gemm3_hip_us"] = timed(lambda: A.gemm_rows(h2, w3t, lg, w_transposed=True, bias=b3p))
 res["gemm2_torch_us"] = timed(lambda: torch.addmm(b2, x, w2, out=h2b).clamp_(0, 6))
 res["gemm3_torch_us"] = timed(lambda: torch.addmm(b3, h2b, w3, out=lgb))
+u = torch.rand(N, device=dev, generator=g); act = torch.empty(N, dtype=torch.int64, device=dev)
+res["head_fused_us"] = timed(lambda: A.actor_head(x, w2t, b2, w3t, b3p, u, NA, h2, lg, act))
+res["sample_us"] = timed(lambda: A.sample_actions(lg[:, :NA], u, out=act))
 res["err2"] = float((h2 - (x @ w2 + b2).clamp(0, 6)).abs().max()); res["err3"] = float((lg[:, :NA] - (h2 @ w3 + b3)).abs().max())
 print(json.dumps(res))
