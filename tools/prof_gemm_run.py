@@ -26,5 +26,17 @@ for _ in range(reps):
     A.gemm_rows(dl, w3p, out, w_transposed=True, relu6_mask_h=h)                                       # dX through the policy head
     A.gemm_tn(x, y, gw2, ws200, dbias_out=gb2)                                                         # dW 200 x 200
     A.gemm_tn(x, dl[:, :NA], gw3, ws625, dbias_out=gb3)                                                # dW 200 x 625
+# one rollout step's actor head at 8192 rows (fused kernel, and the three launches it replaces)
+N = 8192
+xs, us = x[:N].contiguous(), torch.rand(N, device=dev, generator=g)
+w3t = w3p.t().contiguous().t().contiguous() if False else None
+w3tp = torch.zeros(640, H, device=dev); w3tp[:NA] = (torch.rand(NA, H, device=dev, generator=g) - 0.5) * 0.2
+b3p = torch.zeros(640, device=dev)
+h2s, lgs, acts = torch.empty(N, H, device=dev), torch.zeros(N, 640, device=dev), torch.empty(N, dtype=torch.int64, device=dev)
+for _ in range(reps):
+    A.actor_head(xs, w2t, b2, w3tp, b3p, us, NA, h2s, lgs, acts)
+    A.gemm_rows(xs, w2t, h2s, w_transposed=True, bias=b2, relu6=True)
+    A.gemm_rows(h2s, w3tp, lgs, w_transposed=True, bias=b3p)
+    A.sample_actions(lgs[:, :NA], us, out=acts)
 torch.cuda.synchronize()
 print("ok")
