@@ -493,17 +493,28 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
     n = envs * rollout_len * rollouts
     st = runner.stats
     ar_ms, ar_bytes = st.get("allreduce_ms"), grad_allreduce_bytes(runner.net)
-    busbw = (2.0 * (world - 1) / world * ar_bytes / (ar_ms * 1e-3) / 1e9) if (world > 1 and ar_ms) else None
+    ov_ms, buckets = st.get("allreduce_overlapped_ms"), st.get("allreduce_buckets")
+    f = 2.0 * (world - 1) / world
+    busbw = busbw_buckets = None
+    if world > 1 and ar_ms:
+        if buckets and ov_ms:     # two buckets: the critic trunk's (hidden behind the actor's backward pass) and the actor trunk's (exposed)
+            busbw = f * sum(buckets) / ((ov_ms + ar_ms) * 1e-3) / 1e9
+            busbw_buckets = [f * buckets[0] / (ov_ms * 1e-3) / 1e9, f * buckets[1] / (ar_ms * 1e-3) / 1e9]
+        else:
+            busbw = f * ar_bytes / (ar_ms * 1e-3) / 1e9
     return {"metric": "A2C end-to-end env steps/sec (policy + sampling + env step + update incl. gradient all-reduce)",
             "value": whole_job_rate(n, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "envs_per_gpu": envs,
             "rollout_len": rollout_len, "rollouts": rollouts, "ms_per_rollout": elapsed / rollouts * 1e3,
             "collect_ms_per_rollout": prof["collect"] / rollouts * 1e3, "update_ms_per_rollout": prof["update"] / rollouts * 1e3,
             "per_rank_elapsed_s": per_rank,
             "allreduce_ms_per_update": ar_ms, "grad_allreduce_bytes": ar_bytes,
-            "allreduce_busbw_GBps": busbw, "allreduce_busbw_note": "2 (N-1)/N x gradient bytes / all-reduce time of the last update (device "
-            "events around the collective(s)); null at 1 rank.  xGMI ring: 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md)",
+            "allreduce_busbw_GBps": busbw, "allreduce_busbw_per_bucket_GBps": busbw_buckets,
+            "allreduce_busbw_note": "2 (N-1)/N x bytes / time of the last update's collective(s) (device events); with two buckets the time is "
+            "hidden + exposed (allreduce_overlapped_ms + allreduce_ms_per_update: as if they ran one after the other) and the per-bucket figures "
+            "use each bucket's own time; null at 1 rank.  xGMI ring: 7 links x ~153 GB/s per GPU (MI355X_MICROARCH.md)",
             "allreduce_overlapped_ms": st.get("allreduce_overlapped_ms"), "allreduce_buckets": st.get("allreduce_buckets"),
-            "allreduce": ("RCCL (nccl backend), one flat bucket per update" if (world > 1 and args.backend == "nccl")
+            "allreduce": (("RCCL (nccl backend), " + ("two buckets per update: critic trunk on a side stream behind the actor's backward pass, then "
+                           "the actor trunk" if buckets else "one flat bucket per update")) if (world > 1 and args.backend == "nccl")
                           else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
             "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
             "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
