@@ -4,9 +4,11 @@
  * layer on the raveled (nBS+1, G, G) state, 50 000 inputs of which nBS + nUE are non-zero (main.py:190,202).  On the batched path
  * that layer is a sum of nBS + nUE rows of a [N_S, H] table per sample; agent.py keeps the plain PyTorch form
  * (F.embedding_bag(idx, W, mode="sum") + b) as the reference implementation and the CPU path, and uses these kernels on the GPU.
- * The dense layers behind it stay PyTorch-ROCm GEMMs (north_star); ABI 2 adds the kernels around them: index construction and
- * action sampling for the rollout, and for the update the fused loss gradient, relu6 backward with bias gradients, the table
- * gradient (sorted, deterministic) and the TF1 RMSProp step.  Every entry point is asynchronous on `stream` (a hipStream_t,
+ * ABI 2 added the kernels around the dense layers: index construction and action sampling for the rollout, and for the update the
+ * fused loss gradient, relu6 backward with bias gradients, the table gradient (sorted, deterministic) and the TF1 RMSProp step.  ABI 3
+ * adds the dense layers themselves for the reference's widths (200 hidden units, 625 actions): float32 MFMA GEMMs with the relu6 / bias
+ * / relu6-mask / bias-gradient epilogues fused, and the actor's head of a rollout step as one kernel; agent.py keeps torch.mm as the
+ * alternative (hip_gemms=False) and the tests compare the two.  Every entry point is asynchronous on `stream` (a hipStream_t,
  * 0 = the null stream), allocates nothing (workspaces are caller-owned; *_workspace_bytes give their sizes), returns 0 or a
  * negative UAVAGENT_E_* code and never throws; all pointers are device pointers on the current device.
  */

@@ -109,15 +109,15 @@ def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n, rotat
 @pytest.mark.parametrize("n_envs", [8192])
 def test_config5_at_full_size_matches_the_oracle_on_windows(n_envs):
     """BASELINE configs[4]: 16 UAV x 200 UE, 8192 envs -- env_kernel_multipass<16, STEP, cube, FAST> at the 8192 wavefronts
-    profiles/r02e_config5_kernel_stats.csv times -- 8 steps against 8-env oracle windows at the start, in the middle and at the
-    end of the batch.  Integers (cells, serving UAV, outage count, step counter) EXACT over every window and step: the multi-pass
+    profiles/r02e_config5_kernel_stats.csv times -- 40 steps (the handover FIFO is full from step 2 on: ~38 steps of handover decisions)
+    against 16-env oracle windows at the start, in the middle and at the end of the batch.  Integers (cells, serving UAV, outage count, step counter) EXACT over every window and step: the multi-pass
     kernel sums the interference of the best UAV in a different order than the reference, which could only
     show as a flipped handover / outage decision."""
     torch = _torch()
     from drl_uav_cellularnet_amd import BatchedMobiEnv, _capi
     from oracle import oracle as O
 
-    B, U, Gd, W, T = 16, 200, 100, 8, 8
+    B, U, Gd, W, T = 16, 200, 100, 16, 40
     bs_init = [(Gd // 8 + (b // 4) * (Gd // 4), Gd // 8 + (b % 4) * (Gd // 4)) for b in range(B)]      # 4 x 4 lattice (SURVEY 8d C5)
     census0 = {name: cnt for name, _, cnt in _capi.launch_census()}
     env = BatchedMobiEnv(n_envs, nBS=B, nUE=U, grid_n=Gd, groups=[50] * 4, bs_init=bs_init, seed=0x5EED)
