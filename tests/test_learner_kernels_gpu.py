@@ -296,6 +296,36 @@ def test_gemm_rows_wide_output_in_slices():
         A.gemm_rows(x, rnd(200, 640), out)                                 # x @ W with W [K, N]: N > 208 is not built
 
 
+@pytest.mark.parametrize("shape", [(300, 40, 320), (300, 36, 320), (33000, 40, 320), (33000, 36, 320), (33001, 204, 200), (700, 44, 96)],
+                         ids=lambda s: "M%d_K%d_N%d" % s)
+def test_gemm_rows_every_tile_shape_and_epilogue(shape):
+    """The w_transposed kernels come in tile shapes chosen by M (64- or 128-row workgroups), N (7-, 10- or 13-block column slices) and
+    K (LDS-DMA ring when K % 40 == 0, register-staged otherwise): every one of them with every epilogue against float64."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    M, K, N = shape
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + K + N)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
+    x, wt, bias = rnd(M, K), rnd(N, K), rnd(N)
+    h = (rnd(M, N) * 4.0 + 2.0).clamp_(0.0, 6.0)
+    want = x.double() @ wt.double().t()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    A.gemm_rows(x, wt, out, w_transposed=True)
+    assert _rel(out, want) < 1e-5
+    A.gemm_rows(x, wt, out, w_transposed=True, bias=bias, relu6=True)
+    assert _rel(out, (want + bias.double()).clamp(0.0, 6.0)) < 1e-5
+    A.gemm_rows(x, wt, out, w_transposed=True, bias=bias)
+    assert _rel(out, want + bias.double()) < 1e-5
+    A.gemm_rows(x, wt, out, w_transposed=True, relu6_mask_h=h)
+    assert _rel(out, want * ((h > 0) & (h < 6)).double()) < 1e-5
+    if N <= 208:
+        cs, ws = torch.empty(N, device="cuda"), A.gemm_rows_workspace(M, "cuda")
+        A.gemm_rows(x, wt, out, w_transposed=True, relu6_mask_h=h, colsum_out=cs, workspace=ws)
+        wm = want * ((h > 0) & (h < 6)).double()
+        assert float((cs.double() - wm.sum(dim=0)).abs().max()) < 1e-5 * max(1.0, float(wm.abs().sum(dim=0).max()))
+
+
 @pytest.mark.parametrize("n_rows", [8192, 33, 1000])
 def test_actor_head_kernel_equals_the_three_launches(n_rows):
     """uavagent_actor_head_f32 (layer 2 + policy head + inverse-CDF draw in one kernel, a workgroup per 32 rows) against
