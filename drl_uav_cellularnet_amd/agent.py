@@ -308,7 +308,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -337,6 +337,9 @@ class A2CRunner:
         self.overlap_allreduce = bool(overlap_allreduce)
         # fused_head: layer 2, the policy head and the action draw of a rollout step as ONE kernel (uavagent_actor_head_f32)
         self.fused_head = bool(fused_head) and self.hip_gemms and 576 < self.net.n_action <= 640
+        # overlap_dw (one rank, hip_gemms): the three dW GEMMs (MFMA bound, 1.6 ms at config 3) run on a side stream beside the
+        # first-layer table gradient (sort + indexed row sums: memory bound, 2.4 ms) instead of between the dX GEMMs
+        self.overlap_dw = bool(overlap_dw)
         self._side = None
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
@@ -566,6 +569,8 @@ class A2CRunner:
                               "ws_cs": A.gemm_rows_workspace(M, dev)})
             if self._world() > 1 and self.overlap_allreduce:     # one table gradient per trunk: each needs its g rows contiguous
                 self._upd.update({"g_a": f(M, H), "g_c": f(M, H)})
+            elif self.overlap_dw:                                # the critic's dh2 beside the actor's: both outlive the dX chain
+                self._upd["dh_c"] = f(M, H)
         return self._upd
 
     @torch.no_grad()
@@ -609,6 +614,7 @@ class A2CRunner:
         A.a2c_loss_grad(b["logits"], b["v"], target, act, self.beta, b["dv"], gv["a_b3"], b["loss"], b["ws_loss"])
         gv["c_b3"].copy_(b["loss"][2:3].to(torch.float32))
         overlap = hip and ("g_a" in b)
+        rows_done = False
         ae = fl.actor_end
         ev = lambda: torch.cuda.Event(enable_timing=True)
         e_c0 = e_c1 = None
@@ -638,6 +644,28 @@ class A2CRunner:
             A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
             A.gemm_rows(b["dh"], net.a_w2, b["g_a"], w_transposed=True, relu6_mask_h=b["h1a"], colsum_out=gv["a_b1"], workspace=b["ws_cs"])
             A.rows_grad(idx, b["g_a"], H, net.n_state, gv["a_w1"], None, b["ws_rows"])
+        elif hip and "dh_c" in b:
+            # The dX chain first (every product the table gradient waits for), then the three dW GEMMs on a side stream WHILE the main
+            # stream sorts the (row, sample) pairs and sums the indexed rows.  Same kernels on the same operands as the branch below:
+            # the gradient is bit-identical (tests/test_learner_kernels_gpu.py).
+            b["w3p"][:, :net.n_action].copy_(net.a_w3)
+            A.gemm_rows(b["logits_pad"], b["w3p"], b["dh"], w_transposed=True, relu6_mask_h=b["h2a"])
+            A.gemm_rows(b["dh"], net.a_w2, b["gcat"][:, :H], w_transposed=True, relu6_mask_h=b["h1a"], colsum_out=gv["a_b1"],
+                        workspace=b["ws_cs"])
+            A.relu6_bwd(None, b["h2c"], b["dh_c"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
+            A.gemm_rows(b["dh_c"], net.c_w2, b["gcat"][:, H:], w_transposed=True, relu6_mask_h=b["h1c"], colsum_out=gv["c_b1"],
+                        workspace=b["ws_cs"])
+            main = torch.cuda.current_stream(self.dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                A.gemm_tn(b["h2a"], b["logits"], gv["a_w3"], b["ws_tn_a"])
+                A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
+                A.gemm_tn(b["h1c"], b["dh_c"], gv["c_w2"], b["ws_tn_h"])
+            A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
+            main.wait_stream(self._side)
+            rows_done = True
         elif hip:
             # actor trunk backwards: dW3; dh2a = relu6'(h2a) * (dlogits @ W3^T); dW2 + db2; dh1a = relu6'(h1a) * (dh2a @ W2^T) + db1
             b["w3p"][:, :net.n_action].copy_(net.a_w3)
@@ -665,7 +693,7 @@ class A2CRunner:
             torch.mm(b["dh"], net.c_w2.t(), out=b["h2c"])
             A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
         # first-layer tables: both in one sorted pass (one rank, or no overlap)
-        if not overlap:
+        if not overlap and not rows_done:
             A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
         # synchronise and step
         ev0, ev1 = ev(), ev()
@@ -682,7 +710,7 @@ class A2CRunner:
         loss = b["loss"].cpu()                                        # (synchronises)
         self.stats = {"a_loss": float(loss[0]), "c_loss": float(loss[1]), "mean_reward": float(rew_buf.mean()),
                       "grad_elems": n_red, "running_r": self.running_r, "allreduce_ms": ev0.elapsed_time(ev1),
-                      "forward_reused": bool(reuse), "hip_gemms": bool(hip),
+                      "forward_reused": bool(reuse), "hip_gemms": bool(hip), "dw_on_side_stream": bool(rows_done),
                       # two buckets (critic trunk, then actor trunk): the first one's time is hidden behind the actor's backward pass
                       "allreduce_overlapped_ms": e_c0.elapsed_time(e_c1) if overlap else None,
                       "allreduce_buckets": [4 * (fl.n_flat - ae), 4 * ae] if overlap else None}

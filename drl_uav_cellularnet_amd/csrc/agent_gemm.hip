@@ -350,13 +350,13 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const f32x4 *__restrict__ 
 //   NT = true:   Wop = W^T      (W [N, K] row-major: backwards through a layer,  dy @ W^T)
 //   EPI 0 none;  1: + bias[n], then relu6 when asked (tf.nn.relu6);  2: relu6 backwards, C = (0 < H[m, n] < 6) ? sum : 0 with H the
 //   layer's forward output (main.py:147-148,153).
-// One workgroup = 128 rows x all N columns, 4 wavefronts of 32 rows x 13 column blocks (104 accumulator VGPRs), two workgroups per
-// CU so that one computes while the other loads or stores.  K is walked in chunks of 20 (5 k-steps) through double-buffered LDS:
-// the A tile as [row][22] (stride 22: the 16 rows x 2 k of a fragment read fall on 32 different banks), the W tile as [k][208] (NT
-// false) or [n][22] (NT true).  The fast kernel (gemm_rows_vec_kernel) needs 16-byte aligned operands and row strides / K / N that are
-// multiples of 4 floats: float4 staging loads without branches, fragments of k-step s + 1 read while k-step s issues, and an epilogue
-// that goes through LDS so that C (and H) move as whole 16-byte pieces of contiguous rows instead of 64-byte column fragments.
-// gemm_rows_kernel<.., VEC = false> is the general form (dword loads, direct epilogue) for everything else.
+// Four kernels, chosen by uavagent_gemm_rows_f32:
+//   gemm_rows_glds_kernel   dy @ W^T / x @ (W^T)^T, aligned operands, K % 40 == 0: LDS-DMA ring (the learner's shapes: all of them)
+//   gemm_rows_nt_kernel     the same product for any K % 4 == 0: register-staged, k-contiguous tiles, wide fragment reads
+//   gemm_rows_vec_kernel    x @ W with W [K, N] as stored (n-contiguous W tile [k][208], A tile [row][22]: stride 22 puts the 16 rows x
+//                           2 k of a fragment read on 32 different banks), aligned operands: 128 rows x <= 208 columns per workgroup,
+//                           float4 staging without branches, epilogue through LDS
+//   gemm_rows_kernel        the general form (dword loads, direct epilogue) for everything else
 // =====================================================================================================================
 constexpr int kRowsBM = 128, kRowsBK = 20, kRowsLD = 22;
 constexpr int kRowsATile = kRowsBM * kRowsLD;                                   // 2816 floats
@@ -364,7 +364,7 @@ constexpr int kRowsWTile = (kRowsBK * kNP > kNP * kRowsLD) ? kRowsBK * kNP : kNP
 constexpr int kRowsLDC = 212;                                                   // epilogue staging row stride (848 B = 53 x 16)
 static_assert(4 * 16 * kRowsLDC <= 2 * (kRowsATile + kRowsWTile), "epilogue staging must fit the tile buffers");
 
-template <bool NT, int EPI>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
                                                                 int K, int N, long long M, const float *__restrict__ bias, int relu6,
                                                                 const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc,
@@ -394,13 +394,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int idx = tid + 256 * i;
-        if (NT) {     // W [N, K]: tile row = n, 5 float4 of k per row
-            const int row = idx / 5, c4 = idx - row * 5;
-            w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = row * kRowsLD + c4 * 4; w_k[i] = c4 * 4; w_ok[i] = row < N;
-        } else {      // W [K, N]: tile row = k (20), N / 4 float4 per row
-            const int row = idx / n4, c4 = idx - row * n4;
-            w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = row * kNP + c4 * 4; w_k[i] = row; w_ok[i] = row < kRowsBK;
-        }
+        const int row = idx / n4, c4 = idx - row * n4;       // W [K, N]: tile row = k (20), N / 4 float4 per row
+        w_g[i] = row * (int)ldw + c4 * 4; w_l[i] = row * kNP + c4 * 4; w_k[i] = row; w_ok[i] = row < kRowsBK;
     }
     float4 va[NA], vw[NW];
     const float *gA = A + m0 * lda;
@@ -409,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__re
 #pragma unroll
         for (int i = 0; i < NA; ++i) va[i] = ldraw4(gA + k0 + a_g[i], a_ok[i] && (k0 + a_k[i] < K), A);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) vw[i] = ldraw4(W + (NT ? (long long)k0 : (long long)k0 * ldw) + w_g[i], w_ok[i] && (k0 + w_k[i] < K), W);
+        for (int i = 0; i < NW; ++i) vw[i] = ldraw4(W + (long long)k0 * ldw + w_g[i], w_ok[i] && (k0 + w_k[i] < K), W);
     };
     auto store_chunk = [&](int buf, int c) {
         const int k0 = c * kRowsBK;
@@ -424,11 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__re
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             if (w_ok[i]) {
-                const float4 v = mask_f4(vw[i], k0 + w_k[i] < K);
-                if (NT) {
-                    float2 *d = reinterpret_cast<float2 *>(dW + w_l[i]);
-                    d[0] = float2{v.x, v.y}; d[1] = float2{v.z, v.w};
-                } else *reinterpret_cast<float4 *>(dW + w_l[i]) = v;
+                *reinterpret_cast<float4 *>(dW + w_l[i]) = mask_f4(vw[i], k0 + w_k[i] < K);
             }
     };
 
@@ -442,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__re
     load_chunk(0);
     store_chunk(0, 0);
     __syncthreads();
-    const int fa = (wave * 32 + r) * kRowsLD + q, fw = NT ? (r * kRowsLD + q) : (q * kNP + r);
+    const int fa = (wave * 32 + r) * kRowsLD + q, fw = q * kNP + r;
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) load_chunk(c + 1);
@@ -453,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_vec_kernel(const float *__re
 #define ROWS_READ(KS, S, L)                                                                                                  \
         do {                                                                                                                \
             if ((L) < 2) a[S][(L) < 2 ? (L) : 0] = tA[(L) * 16 * kRowsLD + (KS) * 4];                                       \
-            else b[S][(L) >= 2 ? (L) - 2 : 0] = NT ? tW[((L) - 2) * 16 * kRowsLD + (KS) * 4] : tW[(KS) * 4 * kNP + ((L) - 2) * 16]; \
+            else b[S][(L) >= 2 ? (L) - 2 : 0] = tW[(KS) * 4 * kNP + ((L) - 2) * 16];                                               \
         } while (0)
 #pragma unroll
         for (int l = 0; l < kRB + 2; ++l) ROWS_READ(0, 0, l);
@@ -1421,17 +1412,11 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
         else if (epi == 1) hipLaunchKernelGGL((gemm_rows_nt_kernel<BM_, NB_, 1>), g2, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
         else hipLaunchKernelGGL((gemm_rows_nt_kernel<BM_, NB_, 2>), g2, blk, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
     } while (0)
-#define UAV_ROWS_E(NT_)                                                                                              \
+#define UAV_ROWS_E(NT_)        /* the general form: dword loads */                                                    \
     do {                                                                                                             \
-        if (vec) {                                                                                                   \
-            if (epi == 0) hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 0>), UAV_ARGS, colp);                         \
-            else if (epi == 1) hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 1>), UAV_ARGS, colp);                    \
-            else hipLaunchKernelGGL((gemm_rows_vec_kernel<NT_, 2>), UAV_ARGS, colp);                                  \
-        } else {                                                                                                     \
-            if (epi == 0) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 0>), UAV_ARGS);                            \
-            else if (epi == 1) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 1>), UAV_ARGS);                       \
-            else hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 2>), UAV_ARGS);                                     \
-        }                                                                                                            \
+        if (epi == 0) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 0>), UAV_ARGS);                                \
+        else if (epi == 1) hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 1>), UAV_ARGS);                           \
+        else hipLaunchKernelGGL((gemm_rows_kernel<NT_, false, 2>), UAV_ARGS);                                         \
     } while (0)
 #define UAV_GL(BM_, NB_, NS_)                                                                                         \
     do {                                                                                                             \
@@ -1454,7 +1439,11 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
         else if (n <= 208) UAV_NT(128, 13);
         else UAV_NT(128, 10);
     } else if (w_transposed) UAV_ROWS_E(true);
-    else UAV_ROWS_E(false);
+    else if (vec) {                                     // x @ W with W [K, N] as stored: n-contiguous W tile, register-staged
+        if (epi == 0) hipLaunchKernelGGL((gemm_rows_vec_kernel<0>), UAV_ARGS, colp);
+        else if (epi == 1) hipLaunchKernelGGL((gemm_rows_vec_kernel<1>), UAV_ARGS, colp);
+        else hipLaunchKernelGGL((gemm_rows_vec_kernel<2>), UAV_ARGS, colp);
+    } else UAV_ROWS_E(false);
 #undef UAV_NT
 #undef UAV_GL
 #undef UAV_ROWS_E
