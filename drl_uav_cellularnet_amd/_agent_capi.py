@@ -1,4 +1,4 @@
-"""ctypes binding of libuavagent.so (include/uavagent.h, ABI 3) and the autograd wrapper agent.py uses for CUDA tensors.
+"""ctypes binding of libuavagent.so (include/uavagent.h, ABI 4) and the autograd wrapper agent.py uses for CUDA tensors.
 
 The plain PyTorch forms stay in agent.py as the reference implementations and the CPU path.  Here: thin launch wrappers (no
 allocation beyond outputs, current torch stream) for the first layer, index construction, action sampling and the pieces of
@@ -12,12 +12,13 @@ import torch
 from . import build as _build
 
 EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_sum_f32", "uavagent_first_layer_f32",
+           "uavagent_first_layer_from_obs_f32",
            "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
            "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
            "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32",
            "uavagent_debug_tn_plan_check", "uavagent_actor_head_f32")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -46,6 +47,7 @@ def load():
         "uavagent_sparse_rows_sum_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _P],
         "uavagent_first_layer_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _I32, _P],
         "uavagent_obs_indices": [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P],
+        "uavagent_first_layer_from_obs_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I64, _I32, _P, _P],
         "uavagent_sample_actions": [_P, _I64, _P, _I64, _I32, _P, _P, _P],
         "uavagent_a2c_loss_grad": [_P, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P],
         "uavagent_relu6_bwd": [_P, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P],
@@ -126,6 +128,31 @@ def sparse_rows_sum(idx, w_a, b_a, w_c=None, b_c=None, relu6=False, out_a=None, 
         rc = lib.uavagent_first_layer_f32(_ptr(w_a), _ptr(b_a), _ptr(out_a), _ptr(w_c), _ptr(b_c), _ptr(out_c), _ptr(idx),
                                           M, K, H, S, 1 if relu6 else 0, _stream(idx.device))
     _check(rc, "uavagent_first_layer_f32")
+    return out_a if w_c is None else (out_a, out_c)
+
+
+def first_layer_from_obs(obs, grid_n, w_a, b_a, w_c, b_c, out_a, out_c, idx_out=None, relu6=True):
+    """obs_indices + sparse_rows_sum in one launch (the rollout loop): obs = env.observation(); the index list of every env is built in
+    the kernel, stored to idx_out [N, B + U] (or not, when None) and summed.  Same bits as the two separate launches."""
+    ue, bs, srv = obs["ue_xy"], obs["bs_xy"], obs["serving"]
+    if ue.dtype != torch.int16 or bs.dtype != torch.int32 or srv.dtype != torch.int8:
+        raise UavAgentError("first_layer_from_obs needs the env's compact observation dtypes (int16 / int32 / int8)")
+    if not (ue.is_contiguous() and bs.is_contiguous() and srv.is_contiguous()):
+        raise UavAgentError("first_layer_from_obs needs contiguous observation arrays")
+    N, U, B = ue.shape[0], ue.shape[1], bs.shape[1]
+    S, H = w_a.shape
+    for t in (w_a, b_a, w_c, b_c, out_a, out_c):
+        if t is not None and (t.dtype != torch.float32 or t.device != ue.device or not t.is_contiguous()):
+            raise UavAgentError("tables, biases and outputs must be contiguous float32 on the device of the observation")
+    if (w_c is None) != (out_c is None) or out_a.shape != (N, H) or (out_c is not None and out_c.shape != (N, H)):
+        raise UavAgentError("outputs must be [N, H]; w_c and out_c go together")
+    if idx_out is not None and (idx_out.shape != (N, B + U) or idx_out.dtype != torch.int64 or not idx_out.is_contiguous()):
+        raise UavAgentError("idx_out must be contiguous int64 [N, B + U]")
+    with torch.cuda.device(ue.device):
+        rc = load().uavagent_first_layer_from_obs_f32(_ptr(w_a), _ptr(b_a), _ptr(out_a), _ptr(w_c), _ptr(b_c), _ptr(out_c), _ptr(ue), _ptr(bs),
+                                                      _ptr(srv), N, U, B, int(grid_n), H, S, 1 if relu6 else 0, _ptr(idx_out),
+                                                      _stream(ue.device))
+    _check(rc, "uavagent_first_layer_from_obs_f32")
     return out_a if w_c is None else (out_a, out_c)
 
 

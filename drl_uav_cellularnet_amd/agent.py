@@ -308,7 +308,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=True):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=True, fused_obs=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -340,6 +340,9 @@ class A2CRunner:
         # overlap_dw (one rank, hip_gemms): the three dW GEMMs (MFMA bound, 1.6 ms at config 3) run on a side stream beside the
         # first-layer table gradient (sort + indexed row sums: memory bound, 2.4 ms) instead of between the dX GEMMs
         self.overlap_dw = bool(overlap_dw)
+        # fused_obs: steps 1 .. T-1 of a rollout build their index list inside the first layer's kernel (uavagent_first_layer_from_obs_f32)
+        # instead of a separate obs_indices launch after every env step
+        self.fused_obs = bool(fused_obs) and env.nBS + env.nUE <= 64
         self._side = None
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
@@ -408,8 +411,13 @@ class A2CRunner:
             from . import _agent_capi as A
         fw = self._fwd
         wt = self._wt if cuda else None
+        fused_obs = cuda and self.fused_obs
         for t in range(T):
-            if cuda:
+            if cuda and fused_obs and t > 0:
+                # the index list of step t is built from the observation step t - 1 left behind, inside the gather (and stored)
+                A.first_layer_from_obs(env.observation(), self.G, net.a_w1, net.a_b1, net.c_w1, net.c_b1, fw["h1a"][t], fw["h1c"][t],
+                                       idx_out=self.idx_buf[t])
+            elif cuda:
                 # both trunks' first layers in one gather (tried twice, round 2 and round 3: the critic's half on a second stream beside
                 # the actor's GEMMs is SLOWER, 6.3-6.4 against 5.5 ms per rollout: two 800-byte gathers cost more than one of 1600)
                 A.sparse_rows_sum(self.idx_buf[t], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][t],
@@ -430,7 +438,8 @@ class A2CRunner:
                 prob = net.actor_only(self.idx_buf[t])
                 self.act_buf[t] = sample_actions(prob, uniforms=self.u_buf[t])
             env.step(self.act_buf[t], reward_out=self.rew_buf[t])
-            self._indices_into(self.idx_buf[t + 1])
+            if not fused_obs or t == T - 1:
+                self._indices_into(self.idx_buf[t + 1])
 
     @torch.no_grad()
     def collect(self):

@@ -42,19 +42,45 @@ __device__ __forceinline__ float4 relu6_4(float4 v) {
     v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
     return v;
 }
-template <bool TWO, int KT, int UNR, bool RELU6>
+// OBS: the index list is not read but BUILT, from the env's compact observation of sample (= env) m -- agent.obs_to_indices /
+// obs_indices_kernel (agent_learner.hip) folded into the gather: node k < B is UAV k in plane 0, node k >= B is UE k - B in plane
+// 1 + its serving UAV (mobile_env.py:169-170), row = (plane * G + x) * G + y, -1 for a node off the grid; the list is also stored
+// (idx_out [M, K], the update's sample record) unless idx_out is null.  One launch less per rollout step.
+struct ObsSrc {
+    const int16_t *ue_xy;       // [M, U, 2]
+    const int32_t *bs_xy;       // [M, B, 2]
+    const int8_t *serving;      // [M, U]
+    long long *idx_out;         // [M, U + B] or null
+    int U, B, G;
+};
+template <bool TWO, int KT, int UNR, bool RELU6, bool OBS>
 __global__ __launch_bounds__(256) void sparse_rows_sum_kernel(const float *__restrict__ wa, const float *__restrict__ ba,
                                                               float *__restrict__ oa, const float *__restrict__ wc,
                                                               const float *__restrict__ bc, float *__restrict__ oc,
                                                               const long long *__restrict__ idx, long long M, int K_rt, int H4,
-                                                              long long n_rows) {
+                                                              long long n_rows, const ObsSrc src) {
     static_assert(KT == 0 || KT % UNR == 0, "the row groups must tile K exactly");
     const int K = KT > 0 ? KT : K_rt;
     const int lane = threadIdx.x & 63;
     const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // the same for all lanes of a wavefront
     if (m >= M) return;
     long long mine = 0;
-    if (lane < K) mine = idx[m * K + lane];
+    if (OBS) {
+        if (lane < K) {
+            int x, y, pl;
+            if (lane < src.B) {
+                const int2 c = reinterpret_cast<const int2 *>(src.bs_xy)[m * src.B + lane];
+                x = c.x; y = c.y; pl = 0;
+            } else {
+                const long long iu = m * src.U + (lane - src.B);
+                const short2 c = reinterpret_cast<const short2 *>(src.ue_xy)[iu];
+                x = c.x; y = c.y; pl = 1 + src.serving[iu];
+            }
+            const bool ok = x >= 0 && x < src.G && y >= 0 && y < src.G && pl >= 0 && pl <= src.B;
+            mine = ok ? ((long long)pl * src.G + x) * src.G + y : -1ll;
+            if (src.idx_out != nullptr) src.idx_out[m * K + lane] = mine;
+        }
+    } else if (lane < K) mine = idx[m * K + lane];
     // An index outside [0, n_rows) means "no row" (agent.obs_to_indices writes -1 for a walker off the grid, and an all -1 list is
     // the reference's all-zero first state): it contributes nothing and is never dereferenced (include/uavagent.h).
     const float wgt = (mine >= 0 && mine < n_rows) ? 1.f : 0.f;
@@ -109,7 +135,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
-extern "C" int uavagent_abi_version(void) { return 3; }
+extern "C" int uavagent_abi_version(void) { return 4; }
 extern "C" const char *uavagent_last_error(void) { return g_err.c_str(); }
 
 extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
@@ -122,28 +148,61 @@ extern "C" int uavagent_sparse_rows_sum_f32(const float *w_a, const float *bias_
     return uavagent_first_layer_f32(w_a, bias_a, out_a, w_c, bias_c, out_c, idx, m_rows, k, h, n_rows, 0, stream);
 }
 
+namespace {
+int first_layer_launch(const float *w_a, const float *bias_a, float *out_a, const float *w_c, const float *bias_c, float *out_c,
+                       const int64_t *idx, const ObsSrc *obs, int64_t m_rows, int32_t k, int32_t h, int64_t n_rows, int32_t relu6,
+                       void *stream);
+}
+
 extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
                                         const float *bias_c, float *out_c, const int64_t *idx, int64_t m_rows, int32_t k,
                                         int32_t h, int64_t n_rows, int32_t relu6, void *stream) {
+    if (m_rows > 0 && !idx) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: null table, output or index pointer");
+    return first_layer_launch(w_a, bias_a, out_a, w_c, bias_c, out_c, idx, nullptr, m_rows, k, h, n_rows, relu6, stream);
+}
+
+extern "C" int uavagent_first_layer_from_obs_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,
+                                                 const float *bias_c, float *out_c, const int16_t *ue_xy, const int32_t *bs_xy,
+                                                 const int8_t *serving, int64_t n_envs, int32_t n_ue, int32_t n_bs, int32_t grid,
+                                                 int32_t h, int64_t n_rows, int32_t relu6, int64_t *idx_out, void *stream) {
+    if (n_ue < 1 || n_bs < 1 || grid < 1 || n_ue + n_bs > 64)
+        return fail(UAVAGENT_E_INVALID, "first_layer_from_obs: need n_ue, n_bs, grid >= 1 and n_ue + n_bs <= 64 (one lane per node)");
+    if (n_envs > 0 && (!ue_xy || !bs_xy || !serving)) return fail(UAVAGENT_E_INVALID, "first_layer_from_obs: null observation pointer");
+    if ((reinterpret_cast<uintptr_t>(ue_xy) & 3u) || (reinterpret_cast<uintptr_t>(bs_xy) & 7u))
+        return fail(UAVAGENT_E_INVALID, "first_layer_from_obs: ue_xy must be 4-byte and bs_xy 8-byte aligned (one cell per load)");
+    if ((long long)(n_bs + 1) * grid * grid > n_rows) return fail(UAVAGENT_E_INVALID, "first_layer_from_obs: the table has fewer than (n_bs + 1) * grid^2 rows");
+    const ObsSrc src = {ue_xy, bs_xy, serving, reinterpret_cast<long long *>(idx_out), n_ue, n_bs, grid};
+    return first_layer_launch(w_a, bias_a, out_a, w_c, bias_c, out_c, nullptr, &src, n_envs, n_ue + n_bs, h, n_rows, relu6, stream);
+}
+
+namespace {
+int first_layer_launch(const float *w_a, const float *bias_a, float *out_a, const float *w_c, const float *bias_c, float *out_c,
+                       const int64_t *idx, const ObsSrc *obs, int64_t m_rows, int32_t k, int32_t h, int64_t n_rows, int32_t relu6,
+                       void *stream) {
     if (m_rows < 0 || n_rows < 1 || k < 1 || k > 64) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: need m_rows >= 0, n_rows >= 1, 1 <= k <= 64");
     if (h < 4 || h > 256 || (h & 3)) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: h must be a multiple of 4 in [4, 256]");
     if ((unsigned long long)n_rows * (unsigned long long)h * 4ull > 0xFFFFFFFFull)
         return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: a table must be smaller than 4 GiB (rows are addressed by 32-bit byte offsets)");
     if (m_rows == 0) return UAVAGENT_OK;      // an empty batch: idx and the outputs may legitimately be null (torch's empty tensors are)
     if ((w_c != nullptr) != (out_c != nullptr)) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: w_c and out_c go together");
-    if (!w_a || !out_a || !idx) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: null table, output or index pointer");
+    if (!w_a || !out_a) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: null table, output or index pointer");
     if (!aligned16(w_a) || !aligned16(out_a) || !aligned16(w_c) || !aligned16(out_c) || !aligned16(bias_a) || !aligned16(bias_c))
         return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: tables, biases and outputs must be 16-byte aligned");
     const long long blocks = (m_rows + 3) / 4;
     if (blocks > 0x7FFFFFFFll) return fail(UAVAGENT_E_INVALID, "sparse_rows_sum: m_rows too large for one launch");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long *ix = reinterpret_cast<const long long *>(idx);
+    const ObsSrc none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+#define UAVAGENT_LAUNCH_(TWO_, KT_, UNR_, R6_, OBS_)                                                                       \
+    hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_, R6_, OBS_>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a, out_a, \
+                       w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows, OBS_ ? *obs : none)
 #define UAVAGENT_LAUNCH(TWO_, KT_, UNR_)                                                                                  \
     do {                                                                                                                  \
-        if (relu6) hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_, true>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a, \
-                                      out_a, w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows);           \
-        else hipLaunchKernelGGL((sparse_rows_sum_kernel<TWO_, KT_, UNR_, false>), dim3((unsigned)blocks), dim3(256), 0, s, w_a, bias_a,     \
-                                out_a, w_c, bias_c, out_c, ix, (long long)m_rows, (int)k, (int)(h / 4), (long long)n_rows);                 \
+        if (obs) {                                                                                                        \
+            if (relu6) UAVAGENT_LAUNCH_(TWO_, KT_, UNR_, true, true); else UAVAGENT_LAUNCH_(TWO_, KT_, UNR_, false, true);  \
+        } else {                                                                                                          \
+            if (relu6) UAVAGENT_LAUNCH_(TWO_, KT_, UNR_, true, false); else UAVAGENT_LAUNCH_(TWO_, KT_, UNR_, false, false); \
+        }                                                                                                                 \
     } while (0)
     if (w_c) {
         if (k == 24) UAVAGENT_LAUNCH(true, 24, 8);
@@ -154,8 +213,10 @@ extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, f
         else if (k == 44) UAVAGENT_LAUNCH(false, 44, 4);
         else UAVAGENT_LAUNCH(false, 0, 1);
     }
+#undef UAVAGENT_LAUNCH_
 #undef UAVAGENT_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(UAVAGENT_E_HIP, std::string("sparse_rows_sum launch: ") + hipGetErrorString(e));
     return UAVAGENT_OK;
 }
+}  // namespace

@@ -8,7 +8,8 @@
  * fused loss gradient, relu6 backward with bias gradients, the table gradient (sorted, deterministic) and the TF1 RMSProp step.  ABI 3
  * adds the dense layers themselves for the reference's widths (200 hidden units, 625 actions): float32 MFMA GEMMs with the relu6 / bias
  * / relu6-mask / bias-gradient epilogues fused, and the actor's head of a rollout step as one kernel; agent.py keeps torch.mm as the
- * alternative (hip_gemms=False) and the tests compare the two.  Every entry point is asynchronous on `stream` (a hipStream_t,
+ * alternative (hip_gemms=False) and the tests compare the two.  ABI 4 adds uavagent_first_layer_from_obs_f32 (index construction folded
+ * into the first layer's gather: one launch less per rollout step).  Every entry point is asynchronous on `stream` (a hipStream_t,
  * 0 = the null stream), allocates nothing (workspaces are caller-owned; *_workspace_bytes give their sizes), returns 0 or a
  * negative UAVAGENT_E_* code and never throws; all pointers are device pointers on the current device.
  */
@@ -25,7 +26,7 @@ extern "C" {
 #define UAVAGENT_E_INVALID (-1)
 #define UAVAGENT_E_HIP (-3)
 
-int uavagent_abi_version(void);   /* 3 */
+int uavagent_abi_version(void);   /* 4 */
 const char *uavagent_last_error(void);
 
 /* out_a[m, :] = sum_k w_a[idx[m, k], :] + bias_a   (k ascending, fp32; bias added last, like embedding_bag(...) + b)
@@ -50,6 +51,16 @@ int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a
  * first, then every UE in the plane of its serving UAV; a cell outside the grid becomes -1.  = agent.obs_to_indices. */
 int uavagent_obs_indices(const int16_t *ue_xy, const int32_t *bs_xy, const int8_t *serving, int64_t n_envs, int32_t n_ue,
                          int32_t n_bs, int32_t grid, int64_t *idx_out, void *stream);
+
+/* ABI 4: uavagent_obs_indices + uavagent_first_layer_f32 in ONE launch, for the rollout loop (a2c_single_thread.py:153-158: the state
+ * env.step returned is raveled and fed to the networks).  Sample m = env m; its index list is built from the compact observation
+ * exactly as uavagent_obs_indices builds it (node k < n_bs: UAV k, plane 0; else UE k - n_bs in plane 1 + serving; -1 off the grid),
+ * stored to idx_out [n_envs, n_bs + n_ue] unless idx_out is NULL, and summed as uavagent_first_layer_f32 sums it (same order, same
+ * bits).  n_bs + n_ue <= 64; n_rows >= (n_bs + 1) * grid^2; ue_xy 4-byte and bs_xy 8-byte aligned. */
+int uavagent_first_layer_from_obs_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c, const float *bias_c,
+                                      float *out_c, const int16_t *ue_xy, const int32_t *bs_xy, const int8_t *serving, int64_t n_envs,
+                                      int32_t n_ue, int32_t n_bs, int32_t grid, int32_t h, int64_t n_rows, int32_t relu6,
+                                      int64_t *idx_out, void *stream);
 
 /* choose_action (main.py:165-169): p = softmax(logits[n, :]); np.random.choice(n_actions, p=p) with the uniform u[n] supplied by
  * the caller: the first a with cumsum(p)[a] > u[n] * cumsum(p)[-1].  logits f32 [n_rows, n_actions] with row stride ld_logits floats

@@ -47,7 +47,7 @@ def test_agent_library_exports_its_header():
     names = sorted(set(re.findall(r"\b(uavagent_[a-z0-9_]+)\s*\(", text)))
     lib = _agent_capi.load()
     assert set(names) == set(_agent_capi.EXPORTS) and all(hasattr(lib, n) for n in names)
-    assert lib.uavagent_abi_version() == _agent_capi.ABI_VERSION == 3
+    assert lib.uavagent_abi_version() == _agent_capi.ABI_VERSION == 4
     assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 1, 24, 200, 100, None) == -1
     assert b"null" in lib.uavagent_last_error()
     assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 0, 24, 200, 100, None) == 0   # empty batch

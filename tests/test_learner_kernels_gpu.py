@@ -33,6 +33,64 @@ def test_obs_indices_kernel_equals_obs_to_indices():
     assert int(got[5, 4 + 3]) == -1 and int(got[9, 4]) == -1 and int((got < 0).sum()) == 2
 
 
+@pytest.mark.parametrize("n_envs,n_ue,groups,two", [(777, 20, [5, 5, 5, 5], True), (130, 40, None, True), (65, 20, [5, 5, 5, 5], False),
+                                                     (33, 12, [3, 3, 3, 3], True)])
+def test_first_layer_from_obs_equals_obs_indices_then_first_layer(n_envs, n_ue, groups, two):
+    """uavagent_first_layer_from_obs_f32 (ABI 4) = uavagent_obs_indices + uavagent_first_layer_f32, bit for bit: the stored index list and
+    both trunks' activations, for the K = 24 / 44 instantiations and the run-time-K one, with off-grid walkers (-1 = no row)."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, _agent_capi as A
+
+    kw = {} if groups is None else {"groups": groups}
+    env = BatchedMobiEnv(n_envs, nBS=4, nUE=n_ue, grid_n=100, **kw)
+    for t in range(3):
+        env.step(torch.randint(0, 625, (n_envs,), device=env.device))
+    obs = {k: v.clone() for k, v in env.observation().items()}
+    obs["ue_xy"][5, 3, 0] = 100
+    obs["ue_xy"][9, 0, 1] = -1
+    obs["ue_xy"][11] = -5                                          # a whole env's walkers off the grid: only its UAV rows count
+    g = torch.Generator(device="cuda").manual_seed(11)
+    S, H = 5 * 100 * 100, 200
+    wa, wc = torch.randn(S, H, device="cuda", generator=g), torch.randn(S, H, device="cuda", generator=g)
+    ba, bc = torch.randn(H, device="cuda", generator=g), torch.randn(H, device="cuda", generator=g)
+    idx = A.obs_indices(obs, 100, 4)
+    for relu6 in (True, False):
+        want = A.sparse_rows_sum(idx, wa, ba, wc if two else None, bc if two else None, relu6=relu6)
+        oa, oc = torch.full((n_envs, H), 7.0, device="cuda"), (torch.full((n_envs, H), 7.0, device="cuda") if two else None)
+        idx_out = torch.full_like(idx, 12345)
+        A.first_layer_from_obs(obs, 100, wa, ba, wc if two else None, bc if two else None, oa, oc, idx_out=idx_out, relu6=relu6)
+        assert torch.equal(idx_out, idx)
+        if two:
+            assert torch.equal(oa, want[0]) and torch.equal(oc, want[1])
+        else:
+            assert torch.equal(oa, want)
+        oa2 = torch.empty_like(oa)
+        A.first_layer_from_obs(obs, 100, wa, ba, None, None, oa2, None, idx_out=None, relu6=relu6)       # no index list asked for
+        assert torch.equal(oa2, want[0] if two else want)
+    with pytest.raises(A.UavAgentError):                          # a table too small for (n_bs + 1) * G^2 rows
+        A.first_layer_from_obs(obs, 100, wa[:40000], ba, None, None, oa, None)
+
+
+def test_rollout_with_index_lists_built_in_the_gather_is_the_same_rollout():
+    """A2CRunner(fused_obs=True), the default, against the separate obs_indices launch per step: the same samples, actions, rewards,
+    activations and, after the update, parameters -- bit for bit, through the captured graph."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner
+
+    runs = []
+    for fused in (True, False):
+        env = BatchedMobiEnv(512, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+        r = A2CRunner(env, rollout=7, fused_obs=fused)
+        assert r.fused_obs == fused
+        for _ in range(3):
+            r.train_rollout()
+        idx, act, rew, boot = r.collect()
+        runs.append((idx.clone(), act.clone(), rew.clone(), boot.clone(), r._fwd["h1c"].clone(), r.idx_buf.clone(), r.flat.w.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 def test_sample_actions_kernel_is_the_inverse_cdf_draw():
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
