@@ -57,6 +57,17 @@ def test_agent_library_exports_its_header():
     assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 1, 24, 200, 2 ** 40, None) == -1
     assert b"4 GiB" in lib.uavagent_last_error()
     assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 0, 24, 200, 100, None) == 0   # m_rows = 0: no launch
+    # ABI 4: the same layer fed from the compact observation (argument order: tables, ue_xy, bs_xy, serving, n_envs, n_ue, n_bs, grid, h, n_rows)
+    flo = lib.uavagent_first_layer_from_obs_f32
+    assert flo(one, None, one, None, None, None, one, one, one, 8, 61, 4, 100, 200, 50000, 1, None, None) == -1
+    assert b"<= 64" in lib.uavagent_last_error()                    # one lane per node of an env
+    assert flo(one, None, one, None, None, None, one, one, one, 8, 20, 4, 100, 200, 49999, 1, None, None) == -1
+    assert b"(n_bs + 1) * grid^2" in lib.uavagent_last_error()      # a table the indices could run past
+    assert flo(one, None, one, None, None, None, None, one, one, 8, 20, 4, 100, 200, 50000, 1, None, None) == -1
+    assert b"null observation" in lib.uavagent_last_error()
+    assert flo(one, None, one, None, None, None, ctypes.c_void_p(18), one, one, 8, 20, 4, 100, 200, 50000, 1, None, None) == -1
+    assert b"aligned" in lib.uavagent_last_error()
+    assert flo(one, None, one, None, None, None, one, one, one, 0, 20, 4, 100, 200, 50000, 1, None, None) == 0     # no envs: no launch
 
 
 def test_gemm_host_logic_without_gpu():
