@@ -15,7 +15,7 @@ EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_
            "uavagent_first_layer_from_obs_f32",
            "uavagent_obs_indices", "uavagent_sample_actions", "uavagent_loss_grad_workspace_bytes", "uavagent_a2c_loss_grad",
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
-           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
+           "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_rows_grad_sort", "uavagent_rows_grad_sums_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
            "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32",
            "uavagent_debug_tn_plan_check", "uavagent_actor_head_f32")
 ABI_VERSION = 4
@@ -53,6 +53,8 @@ def load():
         "uavagent_relu6_bwd": [_P, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P],
         "uavagent_rowdot_f32": [_P, _P, _P, _I64, _I32, _P, _P],
         "uavagent_rows_grad_f32": [_P, _P, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, C.c_size_t, _P],
+        "uavagent_rows_grad_sort": [_P, _I64, _I32, _I32, _I64, _P, C.c_size_t, _P],
+        "uavagent_rows_grad_sums_f32": [_P, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, C.c_size_t, _P],
         "uavagent_nstep_returns_f32": [_P, _P, _I64, _I32, _F, _P, _P],
         "uavagent_rmsprop_tf1": [_P, _P, _P, _I64, _F, _F, _F, _F, _P],
         "uavagent_gemm_rows_f32": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
@@ -245,6 +247,30 @@ def rows_grad(idx, g, h, n_rows, dw0, dw1, ws):
         rc = load().uavagent_rows_grad_f32(_ptr(idx), _ptr(g), M, K, int(h), n_tables, int(n_rows), _ptr(dw0), _ptr(dw1),
                                            C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream(g.device))
     _check(rc, "uavagent_rows_grad_f32")
+
+
+def rows_grad_sort(idx, n_cols_total, n_rows, ws):
+    """First half of rows_grad: the stable sort of the (row, sample) pairs into ws (needs only idx; current stream)."""
+    if idx.dtype != torch.int64 or idx.dim() != 2 or not idx.is_contiguous():
+        raise UavAgentError("idx must be contiguous int64 [M, K]")
+    M, K = idx.shape
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(idx.device):
+        rc = load().uavagent_rows_grad_sort(_ptr(idx), M, K, int(n_cols_total), int(n_rows), C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
+                                            _stream(idx.device))
+    _check(rc, "uavagent_rows_grad_sort")
+
+
+def rows_grad_sums(idx_shape, g, h, n_rows, dw0, dw1, ws):
+    """Second half: the segmented sums over the pairs rows_grad_sort left in ws (same idx; ordered behind the sort by the caller)."""
+    _f32c(g, "g")
+    M, K = idx_shape
+    n_tables = g.shape[1] // h
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(g.device):
+        rc = load().uavagent_rows_grad_sums_f32(_ptr(g), M, K, int(h), n_tables, int(n_rows), _ptr(dw0), _ptr(dw1),
+                                                C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream(g.device))
+    _check(rc, "uavagent_rows_grad_sums_f32")
 
 
 def nstep_returns(rewards, bootstrap, gamma, out=None):

@@ -599,6 +599,25 @@ class A2CRunner:
         idx, act = idx_buf.reshape(M, K), act_buf.reshape(M)
         gv = fl.gv
         hip = self.hip_gemms
+        # The table gradient's sort needs only idx: on the side stream, beside the forward pass and the dX chain (hip path; one sort
+        # serves both trunks' sums when they are exchanged separately).
+        early_sort = hip and self.overlap_dw and idx.is_contiguous()
+        if early_sort:
+            main = torch.cuda.current_stream(self.dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                A.rows_grad_sort(idx, 2 * H, net.n_state, b["ws_rows"])
+            sorted_ev = torch.cuda.Event()
+            sorted_ev.record(self._side)
+
+        def table_grad(g, dw0, dw1):
+            if early_sort:
+                torch.cuda.current_stream(self.dev).wait_event(sorted_ev)
+                A.rows_grad_sums((M, K), g, H, net.n_state, dw0, dw1, b["ws_rows"])
+            else:
+                A.rows_grad(idx, g, H, net.n_state, dw0, dw1, b["ws_rows"])
         # forward: the actor's activations and both first layers were computed by the rollout itself, with these very weights
         reuse = b["own"] and self._fwd_valid and idx_buf.data_ptr() == self.idx_buf.data_ptr()
         if not reuse:
@@ -633,7 +652,7 @@ class A2CRunner:
             A.relu6_bwd(None, b["h2c"], b["dh"], H, gv["c_b2"], b["ws_relu"], dv=b["dv"], w3=net.c_w3, dw3_out=gv["c_w3"])
             A.gemm_tn(b["h1c"], b["dh"], gv["c_w2"], b["ws_tn_h"])
             A.gemm_rows(b["dh"], net.c_w2, b["g_c"], w_transposed=True, relu6_mask_h=b["h1c"], colsum_out=gv["c_b1"], workspace=b["ws_cs"])
-            A.rows_grad(idx, b["g_c"], H, net.n_state, gv["c_w1"], None, b["ws_rows"])
+            table_grad(b["g_c"], gv["c_w1"], None)
             main = torch.cuda.current_stream(self.dev)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.dev)
@@ -652,7 +671,7 @@ class A2CRunner:
             A.gemm_rows(b["logits_pad"], b["w3p"], b["dh"], w_transposed=True, relu6_mask_h=b["h2a"])
             A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
             A.gemm_rows(b["dh"], net.a_w2, b["g_a"], w_transposed=True, relu6_mask_h=b["h1a"], colsum_out=gv["a_b1"], workspace=b["ws_cs"])
-            A.rows_grad(idx, b["g_a"], H, net.n_state, gv["a_w1"], None, b["ws_rows"])
+            table_grad(b["g_a"], gv["a_w1"], None)
         elif hip and "dh_c" in b:
             # The dX chain first (every product the table gradient waits for), then the three dW GEMMs on a side stream WHILE the main
             # stream sorts the (row, sample) pairs and sums the indexed rows.  Same kernels on the same operands as the branch below:
@@ -672,7 +691,7 @@ class A2CRunner:
                 A.gemm_tn(b["h2a"], b["logits"], gv["a_w3"], b["ws_tn_a"])
                 A.gemm_tn(b["h1a"], b["dh"], gv["a_w2"], b["ws_tn_h"], dbias_out=gv["a_b2"])
                 A.gemm_tn(b["h1c"], b["dh_c"], gv["c_w2"], b["ws_tn_h"])
-            A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
+            table_grad(b["gcat"], gv["a_w1"], gv["c_w1"])
             main.wait_stream(self._side)
             rows_done = True
         elif hip:
@@ -703,7 +722,7 @@ class A2CRunner:
             A.relu6_bwd(b["h2c"], b["h1c"], b["gcat"][:, H:], 2 * H, gv["c_b1"], b["ws_relu"])
         # first-layer tables: both in one sorted pass (one rank, or no overlap)
         if not overlap and not rows_done:
-            A.rows_grad(idx, b["gcat"], H, net.n_state, gv["a_w1"], gv["c_w1"], b["ws_rows"])
+            table_grad(b["gcat"], gv["a_w1"], gv["c_w1"])
         # synchronise and step
         ev0, ev1 = ev(), ev()
         ev0.record()

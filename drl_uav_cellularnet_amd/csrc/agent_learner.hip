@@ -636,12 +636,37 @@ extern "C" size_t uavagent_rows_grad_workspace_bytes(int64_t m_rows, int32_t k, 
     return w.total;
 }
 
-extern "C" int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables,
-                                      int64_t n_rows, float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes,
-                                      void *stream) {
+// The two halves of uavagent_rows_grad_f32 (ABI 4).  The sort needs only idx, which a learner has long before g exists: it can run
+// beside the backward pass (another stream), and serve several sums over the same samples (one per trunk).
+extern "C" int uavagent_rows_grad_sort(const int64_t *idx, int64_t m_rows, int32_t k, int32_t n_cols_total, int64_t n_rows, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    if (m_rows < 1 || k < 1 || k > 64 || n_cols_total < 4 || n_cols_total > 512 || (n_cols_total & 3) || n_rows < 1)
+        return fail2(UAVAGENT_E_INVALID, "rows_grad: need m_rows >= 1, 1 <= k <= 64, h a multiple of 4 in [4, 256], 1 or 2 tables");
+    if (!idx || !workspace) return fail2(UAVAGENT_E_INVALID, "rows_grad: null pointer");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail2(UAVAGENT_E_INVALID, "rows_grad: g and the tables must be 16-byte aligned, the workspace 256-byte aligned");
+    const long long n_pairs = (long long)m_rows * k;
+    if (n_pairs > 0x7FFFFFFFll || (unsigned long long)n_rows >= 0xFFFFFFF0ull) return fail2(UAVAGENT_E_INVALID, "rows_grad: too many pairs / rows for 32-bit keys");
+    RowsWs w;
+    if (int rc = rows_ws(n_pairs, n_cols_total, n_rows, w)) return rc;
+    if (workspace_bytes < w.total) return fail2(UAVAGENT_E_INVALID, "rows_grad: workspace smaller than uavagent_rows_grad_workspace_bytes()");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    uint32_t *keys_in = reinterpret_cast<uint32_t *>(ws + w.keys_in), *keys_out = reinterpret_cast<uint32_t *>(ws + w.keys_out);
+    uint32_t *samp_in = reinterpret_cast<uint32_t *>(ws + w.samp_in), *samp_out = reinterpret_cast<uint32_t *>(ws + w.samp_out);
+    hipLaunchKernelGGL(rows_keys_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const long long *>(idx),
+                       n_pairs, (int)k, (uint32_t)n_rows, keys_in, samp_in);
+    if (int rc = launch_ok("rows_grad keys")) return rc;
+    size_t tmp = w.sort_tmp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs(ws + w.sort_tmp, tmp, keys_in, keys_out, samp_in, samp_out, (size_t)n_pairs, 0u, sort_bits(n_rows), s);
+    if (e != hipSuccess) return fail2(UAVAGENT_E_HIP, std::string("rows_grad: rocprim radix_sort_pairs: ") + hipGetErrorString(e));
+    return UAVAGENT_OK;
+}
+
+extern "C" int uavagent_rows_grad_sums_f32(const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables, int64_t n_rows,
+                                           float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes, void *stream) {
     if (m_rows < 1 || k < 1 || k > 64 || h < 4 || h > 256 || (h & 3) || (n_tables != 1 && n_tables != 2) || n_rows < 1)
         return fail2(UAVAGENT_E_INVALID, "rows_grad: need m_rows >= 1, 1 <= k <= 64, h a multiple of 4 in [4, 256], 1 or 2 tables");
-    if (!idx || !g || !dw0_out || (n_tables == 2 && !dw1_out) || !workspace) return fail2(UAVAGENT_E_INVALID, "rows_grad: null pointer");
+    if (!g || !dw0_out || (n_tables == 2 && !dw1_out) || !workspace) return fail2(UAVAGENT_E_INVALID, "rows_grad: null pointer");
     if (!al16(g) || !al16(dw0_out) || !al16(dw1_out) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail2(UAVAGENT_E_INVALID, "rows_grad: g and the tables must be 16-byte aligned, the workspace 256-byte aligned");
     const long long n_pairs = (long long)m_rows * k;
@@ -652,20 +677,13 @@ extern "C" int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_
     if (workspace_bytes < w.total) return fail2(UAVAGENT_E_INVALID, "rows_grad: workspace smaller than uavagent_rows_grad_workspace_bytes()");
     hipStream_t s = (hipStream_t)stream;
     char *ws = reinterpret_cast<char *>(workspace);
-    uint32_t *keys_in = reinterpret_cast<uint32_t *>(ws + w.keys_in), *keys_out = reinterpret_cast<uint32_t *>(ws + w.keys_out);
-    uint32_t *samp_in = reinterpret_cast<uint32_t *>(ws + w.samp_in), *samp_out = reinterpret_cast<uint32_t *>(ws + w.samp_out);
+    const uint32_t *keys_out = reinterpret_cast<const uint32_t *>(ws + w.keys_out), *samp_out = reinterpret_cast<const uint32_t *>(ws + w.samp_out);
     uint32_t *head = reinterpret_cast<uint32_t *>(ws + w.head), *tail = reinterpret_cast<uint32_t *>(ws + w.tail);
     float *carry = reinterpret_cast<float *>(ws + w.carry);
     // rows nobody touches keep a zero gradient
     hipError_t e = hipMemsetAsync(dw0_out, 0, (size_t)n_rows * h * sizeof(float), s);
     if (e == hipSuccess && n_tables == 2) e = hipMemsetAsync(dw1_out, 0, (size_t)n_rows * h * sizeof(float), s);
     if (e != hipSuccess) return fail2(UAVAGENT_E_HIP, std::string("rows_grad: memset: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(rows_keys_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const long long *>(idx),
-                       n_pairs, (int)k, (uint32_t)n_rows, keys_in, samp_in);
-    if (int rc = launch_ok("rows_grad keys")) return rc;
-    size_t tmp = w.sort_tmp_bytes;
-    e = rocprim::radix_sort_pairs(ws + w.sort_tmp, tmp, keys_in, keys_out, samp_in, samp_out, (size_t)n_pairs, 0u, sort_bits(n_rows), s);
-    if (e != hipSuccess) return fail2(UAVAGENT_E_HIP, std::string("rows_grad: rocprim radix_sort_pairs: ") + hipGetErrorString(e));
     const long long chunks = (n_pairs + kChunk - 1) / kChunk;
     const unsigned blocks = (unsigned)((chunks + 3) / 4);
     hipLaunchKernelGGL(rows_sum_stage_a, dim3(blocks), dim3(256), 0, s, keys_out, samp_out, n_pairs, (uint32_t)n_rows, g, (int)(ncol / 4),
@@ -674,6 +692,18 @@ extern "C" int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_
     hipLaunchKernelGGL(rows_sum_stage_b, dim3(blocks), dim3(256), 0, s, head, tail, chunks, carry, (int)(ncol / 4), (int)(h / 4), dw0_out,
                        n_tables == 2 ? dw1_out : dw0_out);
     return launch_ok("rows_grad stage B");
+}
+
+extern "C" int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables,
+                                      int64_t n_rows, float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    if (h < 4 || h > 256 || (h & 3) || (n_tables != 1 && n_tables != 2))
+        return fail2(UAVAGENT_E_INVALID, "rows_grad: need m_rows >= 1, 1 <= k <= 64, h a multiple of 4 in [4, 256], 1 or 2 tables");
+    if (!idx || !g || !dw0_out || (n_tables == 2 && !dw1_out) || !workspace) return fail2(UAVAGENT_E_INVALID, "rows_grad: null pointer");
+    if (!al16(g) || !al16(dw0_out) || !al16(dw1_out) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail2(UAVAGENT_E_INVALID, "rows_grad: g and the tables must be 16-byte aligned, the workspace 256-byte aligned");
+    if (int rc = uavagent_rows_grad_sort(idx, m_rows, k, h * n_tables, n_rows, workspace, workspace_bytes, stream)) return rc;
+    return uavagent_rows_grad_sums_f32(g, m_rows, k, h, n_tables, n_rows, dw0_out, dw1_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int uavagent_rowdot_f32(const float *y, const float *w, const float *bias, int64_t m_rows, int32_t n_cols, float *out,

@@ -98,6 +98,15 @@ int uavagent_rowdot_f32(const float *y, const float *w, const float *bias, int64
 size_t uavagent_rows_grad_workspace_bytes(int64_t m_rows, int32_t k, int32_t n_cols_total, int64_t n_rows);
 int uavagent_rows_grad_f32(const int64_t *idx, const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables,
                            int64_t n_rows, float *dw0_out, float *dw1_out, void *workspace, size_t workspace_bytes, void *stream);
+/* ABI 4: the two halves of uavagent_rows_grad_f32 as calls of their own.  _sort (keys + stable radix sort of the (row, sample) pairs into
+ * the workspace) needs only idx, which exists before the backward pass starts: it may run beside it on another stream, and one sort serves
+ * any number of _sums calls over the same samples (one per trunk when their gradients are exchanged separately).  _sums must see the
+ * workspace a _sort of the same (idx, m_rows, k, n_rows) wrote, after it in stream order (or behind an event); the workspace must hold
+ * uavagent_rows_grad_workspace_bytes for the larger of the two n_cols_total (= h * n_tables). */
+int uavagent_rows_grad_sort(const int64_t *idx, int64_t m_rows, int32_t k, int32_t n_cols_total, int64_t n_rows, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int uavagent_rows_grad_sums_f32(const float *g, int64_t m_rows, int32_t k, int32_t h, int32_t n_tables, int64_t n_rows, float *dw0_out,
+                                float *dw1_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* n-step value targets of a rollout (a2c_single_thread.py:176-183): out[t, n] = r[t, n] + gamma * out[t+1, n], out[T, n] := bootstrap[n]
  * (v(s_T), or 0 where the episode ended).  rewards / out f32 [n_steps, n_envs], bootstrap f32 [n_envs]. */

@@ -234,6 +234,40 @@ def test_rows_grad_matches_the_embedding_bag_backward():
     _rows_grad_case(torch, A, torch.full((10, 4), -1, dtype=torch.int64, device="cuda"), 200, 50, True)   # nothing to add: zeros
 
 
+def test_rows_grad_sort_once_sums_per_trunk_equals_the_single_call():
+    """ABI 4: uavagent_rows_grad_sort + uavagent_rows_grad_sums_f32 against uavagent_rows_grad_f32, bit for bit -- both tables in one sum,
+    and ONE sort (issued for the 2 x H layout, on another stream) serving a sum per trunk (what a rank does that exchanges the trunks'
+    gradients separately)."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    S, H, M, K = 50000, 200, 5003, 24
+    idx = torch.randint(0, S, (M, K), device="cuda", generator=gen)
+    idx[:, 0] = 777
+    idx[::5, 3] = -1
+    g = torch.randn(M, 2 * H, device="cuda", generator=gen)
+    ws = A.rows_grad_workspace(M, K, 2 * H, S, "cuda")
+    want_a, want_c = torch.empty(S, H, device="cuda"), torch.empty(S, H, device="cuda")
+    A.rows_grad(idx, g, H, S, want_a, want_c, ws)
+    ws.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        A.rows_grad_sort(idx, 2 * H, S, ws)
+    torch.cuda.current_stream().wait_stream(side)
+    got_a, got_c = torch.full_like(want_a, 3.0), torch.full_like(want_c, 3.0)
+    A.rows_grad_sums((M, K), g, H, S, got_a, got_c, ws)
+    assert torch.equal(got_a, want_a) and torch.equal(got_c, want_c)
+    ga, gc = g[:, :H].contiguous(), g[:, H:].contiguous()
+    one_a, one_c = torch.full_like(want_a, 3.0), torch.full_like(want_c, 3.0)
+    A.rows_grad_sums((M, K), gc, H, S, one_c, None, ws)             # the same sorted pairs, one table at a time
+    A.rows_grad_sums((M, K), ga, H, S, one_a, None, ws)
+    assert torch.equal(one_a, want_a) and torch.equal(one_c, want_c)
+    with pytest.raises(A.UavAgentError):
+        A.rows_grad_sort(idx, 2 * H, S, ws[:1024])                  # a workspace that cannot hold the pairs
+
+
 def test_rmsprop_kernel_has_tf1_semantics():
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
