@@ -912,19 +912,24 @@ __global__ __launch_bounds__(BM * 4) void gemm_rows_glds_kernel(const float *__r
 // As three launches (two gemm_rows_glds launches + the sampling kernel) a step spends 12 + 26 + 9 us of which about a third is launch,
 // prologue (the first tiles' round trip), epilogue and the re-read of the logits; here a workgroup owns 32 rows from h1 to the action:
 // h1 tile -> LDS (DMA), W2^T streamed through a 2-stage LDS-DMA ring (5 chunks of 40 k), h2 tile kept in LDS (and stored for the update),
-// W3^T streamed through the same ring in two halves of 320 policy columns (10 chunks), all 640 logits of the 32 rows held in the
-// accumulators of the 4 waves, then written to an LDS tile from which the rows are stored (coalesced) and sampled.  Same k order per output
+// W3^T streamed through a 3-stage ring in three parts of 256 / 256 / 128 policy columns (15 chunks), all 640 logits of the 32 rows held in
+// the accumulators of the 8 waves, then written to an LDS tile from which the rows are stored (coalesced) and sampled.  Same k order per output
 // element as gemm_rows_glds_kernel, same arithmetic as sample_actions_kernel: results are bit-identical to the three-launch form.
-// 8 waves, two per SIMD: wave w = row block w & 1, column quarter w >> 1 (4 of 16 column blocks in layer 2 -- 13 are real --, 5 of 20 in each
-// policy half).  (With 4 waves each wave issued 13 LDS-DMA instructions per 100 MFMAs and a lone workgroup took 41 us.)
+// 8 waves, two per SIMD: wave w = row block w & 1, column quarter w >> 1 (4 of 16 column blocks in layer 2 -- 13 are real --, 4 / 4 / 2 of the
+// 16 / 16 / 8 of the policy parts).  (With 4 waves each wave issued 13 LDS-DMA instructions per 100 MFMAs and a lone workgroup took 41 us.
+// Two stages of 320 policy columns against three of 256: 33.5 against 34 us for a lone workgroup, 38.9 us at 8192 rows either way -- the
+// prefetch distance was not what the boundaries cost; a workgroup issues 84 LDS-DMA instructions per wave for its 672 KB of weights.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kHdRows = 32, kHdH = 200, kHdNP = 640, kHdWaves = 8, kHdThr = kHdWaves * 64;
 constexpr int kHdH1F4 = kHdRows * kHdH / 4, kHdH1Pass = (kHdH1F4 + kHdThr - 1) / kHdThr;         // 1600 float4: 4 passes (the last one: 1 wave)
 constexpr int kHdW2Rows = 256, kHdW2Pass = kHdW2Rows * 10 / kHdThr;                              // 2560 float4: 5 passes
-constexpr int kHdW3Rows = 320, kHdW3Pass = (kHdW3Rows * 10 + kHdThr - 1) / kHdThr;               // 3200 float4: 7 passes (the last one: 2 waves)
-constexpr int kHdStageF = kHdW3Rows * kGlBK;                                                    // 12 800 floats per ring stage
+constexpr int kHdW3Rows = 320;                                                                  // (rows of a phase-1 ring stage: 256 used)
+constexpr int kHdStageF = kHdW3Rows * kGlBK;                                                    // 12 800 floats per ring stage (phase 1's two)
+constexpr int kHdPartRows = 256, kHdP3StageF = kHdPartRows * kGlBK, kHdP3Pass = kHdPartRows * 10 / kHdThr;   // phase 2: 10 240 floats per stage, 5 passes
 constexpr int kHdLdsF = 2 * kHdRows * kHdH + 2 * kHdStageF;                                     // 38 400 floats = 153 600 B
-static_assert(kHdW2Rows * kGlBK <= kHdStageF && 2 * kHdStageF >= kHdRows * kHdNP && kHdH1F4 % 64 == 0 && (kHdW3Rows * 10) % 64 == 0, "the head's LDS plan");
+static_assert(kHdW2Rows * kGlBK <= kHdStageF && kHdH1F4 % 64 == 0 && 3 * kHdP3StageF <= kHdRows * kHdH + 2 * kHdStageF &&
+              kHdRows * kHdNP <= kHdRows * kHdH + 2 * kHdStageF && kHdPartRows * 10 % kHdThr == 0 && (kHdNP - 2 * kHdPartRows) * 10 % 64 == 0 &&
+              kHdNP - 2 * kHdPartRows == 128, "the head's LDS plan");
 
 __device__ __forceinline__ float wave_max_g(float v) {
 #pragma unroll
@@ -969,7 +974,9 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
                                                                 float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
                                                                 long long *__restrict__ action) {
     __shared__ __attribute__((aligned(16))) float lds[kHdLdsF];
-    float *const sH1 = lds, *const sH2 = lds + kHdRows * kHdH, *const ring = lds + 2 * kHdRows * kHdH;
+    // [h2 tile | h1 tile | ring]: the policy head (phase 2) no longer needs h1 and runs a THREE-stage ring over [h1 tile | ring]
+    float *const sH2 = lds, *const sH1 = lds + kHdRows * kHdH, *const ring = lds + 2 * kHdRows * kHdH;
+    float *const ring3 = sH1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4, rb = wave & 1, qt = wave >> 1;          // row block, column quarter
     const long long m0 = (long long)blockIdx.x * kHdRows;
@@ -1038,25 +1045,28 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     }
     __syncthreads();                                   // (every wave is past the ring's last read too: phase 2 may refill it)
 
-    // ---- phase 2: logits = h2 @ W3 + b3, two halves of 320 policy columns x 5 chunks: wave = 16 rows x 5 of 20 column blocks ----
-    const float *s3[2][kHdW3Pass];
+    // ---- phase 2: logits = h2 @ W3 + b3 in three PARTS of 256 / 256 / 128 policy columns x 5 chunks of 40 k; wave = 16 rows x 4 / 4 / 2 of a
+    // part's 16 / 16 / 8 column blocks.  Stages of 256 rows x 40 k (40 KB): three of them fit [h1 tile | ring], so chunk p + 2 is issued when
+    // chunk p starts and has two chunk times to land -- with two stages of 320 rows a lone workgroup spent 14 of its 34 us at the 15 chunk
+    // boundaries waiting for loads issued one chunk earlier.  Same k order per output element as before (chunks of 40, same k bijection).
+    const float *s3[2][kHdP3Pass];
 #pragma unroll
-    for (int p = 0; p < kHdW3Pass; ++p) {
-        const int idx = (p * kHdWaves + wave) * 64 + lane, row = idx / 10, c4 = idx - row * 10;
-        const float *g = (row < kHdW3Rows) ? w3t + row * kHdH + c4 * 4 : g_zero16;     // (w3t has 640 rows: rows >= n_act are zeros)
-        s3[0][p] = g;
-        s3[1][p] = (row < kHdW3Rows) ? g + kGlBK : g;
+    for (int p = 0; p < kHdP3Pass; ++p) {
+        const int idx = (p * kHdWaves + wave) * 64 + lane, row = idx / 10, c4 = idx - row * 10;     // row < 256: five passes fill a stage exactly
+        s3[0][p] = w3t + row * kHdH + c4 * 4;
+        s3[1][p] = s3[0][p] + kGlBK;
     }
-    // chunk index p3 = 0..9: half p3 / 5, k chunk p3 % 5; a set is advanced from chunk p to chunk p + 2
-    auto off3 = [](int p3) { return (p3 / 5) * (kHdW3Rows * kHdH) + (p3 % 5) * kGlBK; };
+    // chunk index p3 = 0..14: part p3 / 5, k chunk p3 % 5; a set is advanced from chunk p3 - 2 to chunk p3.  Part 2 has 128 rows = 20 wave
+    // slots: passes 0 and 1 whole, pass 2 for waves 0-3 only (w3t has 640 rows: nothing beyond them is read).
+    auto off3 = [](int p3) { return (p3 / 5) * (kHdPartRows * kHdH) + (p3 % 5) * kGlBK; };
     auto issue3 = [&](auto set_c, int p3) {
         constexpr int SET = decltype(set_c)::value;
-        float *stage = ring + (p3 & 1) * kHdStageF;
+        float *stage = ring3 + (p3 % 3) * kHdP3StageF;
         const int delta = (p3 >= 2) ? off3(p3) - off3(p3 - 2) : 0;
 #pragma unroll
-        for (int p = 0; p < kHdW3Pass; ++p) {
+        for (int p = 0; p < kHdP3Pass; ++p) {
             const int slot = p * kHdWaves + wave;
-            if (slot * 64 < kHdW3Rows * 10) {
+            if (p3 < 10 || slot < (kHdNP - 2 * kHdPartRows) * 10 / 64) {
                 if (p3 >= 2) s3[SET][p] += delta;
                 __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)s3[SET][p], (lds_void_t *)(stage + slot * 256), 16, 0, 0);
             }
@@ -1072,35 +1082,53 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             if (idx < lim) *reinterpret_cast<float4 *>(h2_out + m0 * kHdH + idx * 4) = *reinterpret_cast<const float4 *>(sH2 + idx * 4);
         }
     }
-    f32x4 acc2[2][5];
+    issue3(set1_t{}, 1);
+    f32x4 accA[4], accB[4], accC[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) acc2[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 4; ++c) { accA[c] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    accC[0] = f32x4{0.f, 0.f, 0.f, 0.f}; accC[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *pa2 = sH2 + (rb * 16 + r) * kHdH;
-    auto chunk3 = [&](auto set_c, auto nh_c, int p3) {
-        constexpr int NH = decltype(nh_c)::value;
-        wait_vmcnt<0>();
+    // chunk p3 has landed once at most the loads of chunk p3 + 1 are outstanding (5 per wave; in part 2: 3 for waves 0-3, 2 for the others)
+    auto land3 = [&](int p3) {
+        if (p3 + 1 >= 15) wait_vmcnt<0>();
+        else if (p3 + 1 < 10) wait_vmcnt<kHdP3Pass>();
+        else if (wave < 4) wait_vmcnt<3>();
+        else wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (p3 + 1 < 10) issue3(set_c, p3 + 1);
-        head_chunk<5>(pa2 + (p3 % 5) * kGlBK, ring + (p3 & 1) * kHdStageF + (qt * 5 * 16 + r) * kGlBK, q, acc2[NH]);
     };
-    chunk3(set1_t{}, set0_t{}, 0); chunk3(set0_t{}, set0_t{}, 1); chunk3(set1_t{}, set0_t{}, 2); chunk3(set0_t{}, set0_t{}, 3); chunk3(set1_t{}, set0_t{}, 4);
-    chunk3(set0_t{}, set1_t{}, 5); chunk3(set1_t{}, set1_t{}, 6); chunk3(set0_t{}, set1_t{}, 7); chunk3(set1_t{}, set1_t{}, 8); chunk3(set0_t{}, set1_t{}, 9);
+    auto chunk3 = [&](auto set_c, auto ncb_c, int p3, f32x4 (&acc)[decltype(ncb_c)::value]) {       // SET = parity of p3: chunk p3 + 2 is issued here
+        constexpr int NCB = decltype(ncb_c)::value;
+        land3(p3);
+        if (p3 + 2 < 15) issue3(set_c, p3 + 2);       // its stage was read last in chunk p3 - 1: every wave is past that
+        head_chunk<NCB>(pa2 + (p3 % 5) * kGlBK, ring3 + (p3 % 3) * kHdP3StageF + (qt * NCB * 16 + r) * kGlBK, q, acc);
+    };
+    using n4_t = std::integral_constant<int, 4>;
+    using n2_t = std::integral_constant<int, 2>;
+    chunk3(set0_t{}, n4_t{}, 0, accA); chunk3(set1_t{}, n4_t{}, 1, accA); chunk3(set0_t{}, n4_t{}, 2, accA); chunk3(set1_t{}, n4_t{}, 3, accA); chunk3(set0_t{}, n4_t{}, 4, accA);
+    chunk3(set1_t{}, n4_t{}, 5, accB); chunk3(set0_t{}, n4_t{}, 6, accB); chunk3(set1_t{}, n4_t{}, 7, accB); chunk3(set0_t{}, n4_t{}, 8, accB); chunk3(set1_t{}, n4_t{}, 9, accB);
+    chunk3(set0_t{}, n2_t{}, 10, accC); chunk3(set1_t{}, n2_t{}, 11, accC); chunk3(set0_t{}, n2_t{}, 12, accC); chunk3(set1_t{}, n2_t{}, 13, accC); chunk3(set0_t{}, n2_t{}, 14, accC);
     __syncthreads();                                   // the ring is free: it becomes the [32][640] logits tile
 
     // ---- phase 3: + bias -> logits tile in LDS; coalesced store; one wave samples 4 rows ----
-    float *sL = ring;
+    float *sL = ring3;
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+    for (int cb = 0; cb < 4; ++cb) {
+        const int colA = (qt * 4 + cb) * 16 + r, colB = kHdPartRows + colA;
+        const float bA = b3p[colA], bB = b3p[colB];
 #pragma unroll
-        for (int cb = 0; cb < 5; ++cb) {
-            const int col = nh * kHdW3Rows + (qt * 5 + cb) * 16 + r;
-            const float bv = b3p[col];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) sL[(rb * 16 + 4 * q + t) * kHdNP + col] = acc2[nh][cb][t] + bv;
+        for (int t = 0; t < 4; ++t) {
+            sL[(rb * 16 + 4 * q + t) * kHdNP + colA] = accA[cb][t] + bA;
+            sL[(rb * 16 + 4 * q + t) * kHdNP + colB] = accB[cb][t] + bB;
         }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int colC = 2 * kHdPartRows + (qt * 2 + cb) * 16 + r;
+        const float bC = b3p[colC];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sL[(rb * 16 + 4 * q + t) * kHdNP + colC] = accC[cb][t] + bC;
+    }
     __syncthreads();
     {
         const int rows = (int)(n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows);
