@@ -15,6 +15,7 @@
 // Fragment maps used below (cdna_hip_programming.md section 3): lane l = (r = l & 15, q = l >> 4);
 //   A operand = A[row r][k = q],  B operand = B[k = q][col r],  accumulator register t = C[row 4 q + t][col r].
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -907,6 +908,183 @@ __global__ __launch_bounds__(BM * 4) void gemm_rows_glds_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// dy @ W^T for K = 200, many rows (the update's 200-wide layers), version 6: W^T RESIDENT in LDS, persistent workgroups.
+// Measured on version 4 with its LDS-DMA re-issue compiled out (wrong results, timing only: profiles/r03y_*): a 128-row workgroup at
+// K = 200 lives 62 000 cycles of which 41 600 are its MFMAs -- a third of its life is the prologue (first tiles' round trip), the
+// epilogue and the chunk barriers, with nothing beside it on the CU.  Here none of those recur per tile:
+//   * the grid is one workgroup per CU; workgroups [0, nA) own output columns [0, 112) (7 blocks), the others [112, 208) (6 blocks);
+//     a workgroup loads its 112 x 200 (96 x 200) slice of W^T into LDS ONCE (89.6 / 76.8 KB) and keeps it;
+//   * its 8 wavefronts then walk 16-row tiles of A (tile t of the type's wave list, stride = number of such waves: both types sweep the
+//     rows front to back at the same pace -- 8 nA / 7 = 8 nB / 6 tiles per unit of MFMA work -- so the second read of an A row comes out
+//     of L2 / Infinity Cache); the A fragments go global -> registers (a wave's rows are its own; with the k bijection k = 16 g + 4 q + s
+//     a lane's four k-steps of operands are one 16-byte load), next tile's loads in flight under this tile's 350 (300) MFMAs;
+//   * no barrier after the prologue: W is read-only, a wave's epilogue patch in LDS is its own, and its stores drain under the next
+//     tile's MFMAs (the wave waits for its loads ONCE per tile, before the stores are issued: see arrived4).
+// Column sums (bias gradient of the layer below): per lane over the wave's tiles in ascending order, then the 8 waves, then the
+// workgroups of the type, in order: deterministic.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRsK = 200, kRsThr = 512, kRsWaves = 8, kRsNBA = 7, kRsNBB = 6, kRsG = kRsK / 16;                 // 12 groups of 16 k + 8
+constexpr int kRsLdsF = kRsNBA * 16 * kRsK + kRsWaves * 16 * (kRsNBA * 16 + 4);                                  // 37 248 floats = 148 992 B
+static_assert(kRsK % 16 == 8 && kRsLdsF * 4 <= 160 * 1024, "the resident kernel's LDS plan");
+
+template <int NB, int EPI>
+__device__ __forceinline__ void rows_resident_body(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw, int N,
+                                                   long long M, const float *__restrict__ bias, int relu6, const float *__restrict__ H,
+                                                   long long ldh, float *__restrict__ C, long long ldc, float *__restrict__ col_partial,
+                                                   float *lds, const int n0, const int wg, const int nwg) {
+    constexpr int NC = NB * 16, LDC = NC + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    float *const sW = lds;                                        // [NC][200]
+    float *const E = lds + NC * kRsK + wave * (16 * LDC);         // this wave's epilogue patch [16][LDC]
+    const int nloc = (N - n0 < NC) ? N - n0 : NC;
+
+    // ---- W^T slice -> LDS, once (lane-linear: float4 idx = row * 50 + c4) ----
+    constexpr int WF4 = NC * (kRsK / 4), WSLOTS = (WF4 + 63) / 64;
+#pragma unroll
+    for (int p = 0; p < (WSLOTS + kRsWaves - 1) / kRsWaves; ++p) {
+        const int slot = p * kRsWaves + wave;
+        if (slot < WSLOTS) {
+            const int idx = slot * 64 + lane, row = idx / (kRsK / 4), c4 = idx - row * (kRsK / 4);
+            const float *g = (idx < WF4 && row < nloc) ? W + (long long)(n0 + row) * ldw + c4 * 4 : g_zero16;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sW + slot * 256), 16, 0, 0);
+        }
+    }
+    // ---- tiles of this wave: t = wg * 8 + wave, + nwg * 8, ... ----
+    const long long n_tiles = (M + 15) / 16, stride = (long long)nwg * kRsWaves;
+    long long t = (long long)wg * kRsWaves + wave;
+    f32x4 a4[kRsG], a4n[kRsG];
+    f32x2 a2, a2n;
+    auto load_a = [&](f32x4 (&d4)[kRsG], f32x2 &d2, long long tile) {
+        long long m = (tile < n_tiles ? tile : n_tiles - 1) * 16 + r;                 // (no tile left: any valid rows, never used)
+        m = (m < M) ? m : M - 1;                                                      // rows past M: a valid row, never stored
+        const float *pa = A + m * lda + 4 * q;
+#pragma unroll
+        for (int g = 0; g < kRsG; ++g) d4[g] = *reinterpret_cast<const f32x4 *>(pa + 16 * g);
+        d2 = *reinterpret_cast<const f32x2 *>(A + m * lda + 16 * kRsG + 2 * q);
+    };
+    load_a(a4n, a2n, t);
+    wait_vmcnt<0>();
+    __syncthreads();                                              // W^T is in LDS; the only barrier of the kernel's main part
+
+    const int half = lane >> 5, L = lane & 31;                    // epilogue: lanes 0-31 take even rows, 32-63 odd rows; L = float4 column
+    const bool col_ok = L * 4 < nloc;
+    float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == 1 && bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(bias + n0 + L * 4);
+    if (EPI == 1) arrived4(bv);
+    float4 cs = float4{0.f, 0.f, 0.f, 0.f};
+    const float *pw = sW + r * kRsK + 4 * q;
+    for (; t < n_tiles; t += stride) {
+#pragma unroll
+        for (int g = 0; g < kRsG; ++g) a4[g] = a4n[g];
+        a2 = a2n;
+        load_a(a4n, a2n, t + stride);                              // next tile's A fragments, in flight under this tile's MFMAs
+        f32x4 acc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 w4[2][NB];
+        f32x2 w2[NB];
+        float4 hv[8];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) w4[0][cb] = *reinterpret_cast<const f32x4 *>(pw + cb * 16 * kRsK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < kRsG; ++g) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) {
+                    if (ks == 0) {                                  // operands of the next group, one read ahead of each MFMA
+                        if (g + 1 < kRsG) w4[(g + 1) & 1][cb] = *reinterpret_cast<const f32x4 *>(pw + cb * 16 * kRsK + 16 * (g + 1));
+                        else w2[cb] = *reinterpret_cast<const f32x2 *>(sW + (cb * 16 + r) * kRsK + 16 * kRsG + 2 * q);
+                    }
+                    acc[cb] = MFMA16(a4[g][ks], w4[g & 1][cb][ks], acc[cb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (EPI == 2 && g == kRsG - 3) {                       // the relu6 mask's H rows: late enough to find registers, early enough to land
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long long m = t * 16 + 2 * i + half;
+                    hv[i] = ldraw4(H + m * ldh + n0 + L * 4, col_ok && m < M, H);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                acc[cb] = MFMA16(a2[ks], w2[cb][ks], acc[cb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // ---- epilogue of the tile through the wave's own LDS patch: rows leave as 16-byte pieces of contiguous rows ----
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) E[(4 * q + tt) * LDC + cb * 16 + r] = acc[cb][tt];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ONE wait per tile, before the stores are issued: the next tile's A fragments (issued 350 MFMAs ago) and the H rows have arrived
+#pragma unroll
+        for (int g = 0; g < kRsG; g += 1) asm volatile("" : "+v"(a4n[g]));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a2n));
+#pragma unroll
+        for (int g = 0; g < kRsG; g += 1) asm volatile("" : "+v"(a4n[g]));
+        if (EPI == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) arrived4(hv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 2 * i + half;
+            const long long m = t * 16 + row;
+            if (col_ok && m < M) {
+                float4 v = *reinterpret_cast<const float4 *>(E + row * LDC + L * 4);
+                if (EPI == 1) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (relu6) { v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f); v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f); }
+                }
+                if (EPI == 2) {
+                    const float4 hh = hv[i];
+                    v.x = (hh.x > 0.f && hh.x < 6.f) ? v.x : 0.f; v.y = (hh.y > 0.f && hh.y < 6.f) ? v.y : 0.f;
+                    v.z = (hh.z > 0.f && hh.z < 6.f) ? v.z : 0.f; v.w = (hh.w > 0.f && hh.w < 6.f) ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(C + m * ldc + n0 + L * 4) = v;
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                          // the next tile's patch writes come after these reads
+    }
+    if (col_partial != nullptr) {           // per column: even rows + odd rows of a wave, the waves in order; then the workgroups (rows_colsum_reduce)
+        __syncthreads();
+        float4 *S = reinterpret_cast<float4 *>(lds + NC * kRsK);                 // [8][2][32] float4 over the patches
+        S[(wave * 2 + half) * 32 + L] = cs;
+        __syncthreads();
+        if (wave == 0 && half == 0 && col_ok) {
+            float4 tsum = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < kRsWaves; ++w) {
+                const float4 u0 = S[(w * 2) * 32 + L], u1 = S[(w * 2 + 1) * 32 + L];
+                tsum.x += u0.x + u1.x; tsum.y += u0.y + u1.y; tsum.z += u0.z + u1.z; tsum.w += u0.w + u1.w;
+            }
+            *reinterpret_cast<float4 *>(col_partial + (long long)wg * kNP + n0 + L * 4) = tsum;
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kRsThr, 1) void gemm_rows_resident_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
+                                                                         int N, long long M, const float *__restrict__ bias, int relu6,
+                                                                         const float *__restrict__ H, long long ldh, float *__restrict__ C, long long ldc,
+                                                                         float *__restrict__ col_partial, int nA) {
+    __shared__ __attribute__((aligned(16))) float lds[kRsLdsF];
+    if ((int)blockIdx.x < nA) rows_resident_body<kRsNBA, EPI>(A, lda, W, ldw, N, M, bias, relu6, H, ldh, C, ldc, col_partial, lds, 0, (int)blockIdx.x, nA);
+    else rows_resident_body<kRsNBB, EPI>(A, lda, W, ldw, N, M, bias, relu6, H, ldh, C, ldc, col_partial, lds, kRsNBA * 16, (int)blockIdx.x - nA, (int)gridDim.x - nA);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The actor's head of one rollout step in ONE kernel (choose_action, main.py:165-169 with the network of main.py:147-150):
 //   h2 = relu6(h1 @ W2 + b2);  logits = h2 @ W3 + b3;  action ~ softmax(logits) by the inverse-CDF draw of uavagent_sample_actions.
 // As three launches (two gemm_rows_glds launches + the sampling kernel) a step spends 12 + 26 + 9 us of which about a third is launch,
@@ -1409,6 +1587,9 @@ extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
     return b;
 }
 
+// UAVAGENT_ROWS_RESIDENT=0 (read once): the update's K = 200 GEMMs on version 4's 128-row workgroups instead of the resident-W kernel (A/B runs)
+static const bool g_rows_resident = [] { const char *e = getenv("UAVAGENT_ROWS_RESIDENT"); return e ? e[0] != '0' : true; }();
+
 extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t ldw, int32_t w_transposed, int64_t m_rows, int32_t k,
                                       int32_t n, const float *bias, int32_t relu6, const float *relu6_mask_h, int64_t ldh, float *c, int64_t ldc,
                                       float *colsum_out, void *workspace, size_t workspace_bytes, void *stream) {
@@ -1424,6 +1605,7 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
         return fail3(UAVAGENT_E_INVALID, "gemm_rows: n > 208 needs the aligned w_transposed form (N is then cut into slices)");
     const dim3 grid((unsigned)((m_rows + kRowsBM - 1) / kRowsBM)), blk(256);
     const int epi = relu6_mask_h ? 2 : ((bias || relu6) ? 1 : 0);
+    long long n_part_resident = 0;
     float *colp = nullptr;
     if (colsum_out) {
         if (n > 208) return fail3(UAVAGENT_E_INVALID, "gemm_rows: column sums exist for n <= 208");
@@ -1453,7 +1635,17 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
         else if (epi == 1) hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 1>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
         else hipLaunchKernelGGL((gemm_rows_glds_kernel<BM_, NB_, NS_, 2>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)k, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp); \
     } while (0)
-    if (w_transposed && vec && (k % kGlBK == 0)) {
+    if (w_transposed && vec && k == kRsK && n > kRsNBA * 16 && n <= 208 && m_rows > 32768 && g_rows_resident) {
+        // W^T resident in LDS, persistent workgroups (gemm_rows_resident_kernel): the update's 200-wide layers
+        static const int n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 2) v = 256; return v; }();
+        const int nA = (n_cu * kRsNBA + (kRsNBA + kRsNBB) / 2) / (kRsNBA + kRsNBB) < n_cu ? (n_cu * kRsNBA + (kRsNBA + kRsNBB) / 2) / (kRsNBA + kRsNBB) : n_cu - 1;
+        if (colp && hipMemsetAsync(colp, 0, (size_t)nA * kNP * sizeof(float), st) != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: memset failed");
+        const dim3 g2((unsigned)n_cu), b2(kRsThr);
+        if (epi == 0) hipLaunchKernelGGL((gemm_rows_resident_kernel<0>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp, nA);
+        else if (epi == 1) hipLaunchKernelGGL((gemm_rows_resident_kernel<1>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp, nA);
+        else hipLaunchKernelGGL((gemm_rows_resident_kernel<2>), g2, b2, 0, st, a, (long long)lda, w, (long long)ldw, (int)n, (long long)m_rows, bias, (int)relu6, relu6_mask_h, (long long)ldh, c, (long long)ldc, colp, nA);
+        n_part_resident = nA;
+    } else if (w_transposed && vec && (k % kGlBK == 0)) {
         // LDS-DMA ring (gemm_rows_glds_kernel).  Few rows (a rollout step): 64-row workgroups, N in slices; many rows: 128-row workgroups.
         // (64-row workgroups with a 2-stage ring: two of them fit a CU's LDS and cover each other's prologue / epilogue; measured at 8192
         //  rows against a 3-stage ring with one workgroup per CU: 12.3 vs 13.3 us at N = 200, 26.2 vs 31.2 us at N = 640)
@@ -1477,7 +1669,7 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
 #undef UAV_ROWS_E
 #undef UAV_ARGS
     if (colp) {
-        const long long n_part = (w_transposed && m_rows <= 32768) ? (m_rows + 63) / 64 : (long long)grid.x;     // workgroups along M of the kernel that ran
+        const long long n_part = n_part_resident ? n_part_resident : (w_transposed && m_rows <= 32768) ? (m_rows + 63) / 64 : (long long)grid.x;     // partial rows the kernel that ran wrote
         hipLaunchKernelGGL(rows_colsum_reduce, dim3((n + 63) / 64), dim3(1024), 0, st, colp, n_part, (int)n, colsum_out);
     }
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: launch failed");

@@ -388,11 +388,13 @@ def test_gemm_rows_wide_output_in_slices():
         A.gemm_rows(x, rnd(200, 640), out)                                 # x @ W with W [K, N]: N > 208 is not built
 
 
-@pytest.mark.parametrize("shape", [(300, 40, 320), (300, 36, 320), (33000, 40, 320), (33000, 36, 320), (33001, 204, 200), (700, 44, 96)],
+@pytest.mark.parametrize("shape", [(300, 40, 320), (300, 36, 320), (33000, 40, 320), (33000, 36, 320), (33001, 204, 200), (700, 44, 96),
+                                   (33001, 200, 200), (40000, 200, 132), (33010, 200, 208), (32800, 200, 116), (36000, 200, 112)],
                          ids=lambda s: "M%d_K%d_N%d" % s)
 def test_gemm_rows_every_tile_shape_and_epilogue(shape):
     """The w_transposed kernels come in tile shapes chosen by M (64- or 128-row workgroups), N (7-, 10- or 13-block column slices) and
-    K (LDS-DMA ring when K % 40 == 0, register-staged otherwise): every one of them with every epilogue against float64."""
+    K (LDS-DMA ring when K % 40 == 0, register-staged otherwise; K = 200 with more than 32768 rows and 112 < N <= 208: W^T resident in LDS,
+    persistent workgroups, columns split 112 + the rest): every one of them with every epilogue against float64."""
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
 
