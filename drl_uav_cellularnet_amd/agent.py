@@ -302,9 +302,12 @@ class A2CRunner:
     """Synchronous A2C over a BatchedMobiEnv: every env instance plays the role of one of the reference's workers
     (a2c_single_thread.py:113-118), all stepped by one kernel launch per time step.
 
-    On a GPU the rollout loop is ONE hipGraph (per step: first layer + two GEMMs + sampling kernel + env step + index kernel)
-    and the update is a hand-derived backward pass: PyTorch GEMMs for the dense layers, libuavagent kernels for everything
-    around them.  ``update_reference`` is the same update through autograd; tests compare the two."""
+    On a GPU the rollout loop is ONE hipGraph (per step three kernels: first layer fed from the env's compact observation + the actor's
+    head (layer 2, policy head, action draw) + env step) and the update is a hand-derived backward pass on libuavagent's kernels
+    (float32 MFMA GEMMs with fused epilogues, loss gradient, table gradient, RMSProp).  Every fusion has a switch
+    (``hip_gemms``, ``fused_head``, ``fused_obs``, ``overlap_dw``, ``overlap_allreduce``) whose other setting is the form it replaced; the
+    tests compare the two bit for bit where the arithmetic is the same and to tolerance where it is not.  ``update_reference`` is the same
+    update through autograd."""
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
