@@ -2,7 +2,7 @@
 # round 3: the learner's kernels over whole A2C iterations (8192 envs x 50 steps): kernel trace + separate PMC passes
 # (FETCH_SIZE / WRITE_SIZE / L2 hit counters), digest by tools/pmc_digest.py
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03v
+O=$R/gpurun_out/${TAG:-r03v}
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
