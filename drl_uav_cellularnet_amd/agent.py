@@ -311,7 +311,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=True, fused_obs=True):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -341,8 +341,12 @@ class A2CRunner:
         # fused_head: layer 2, the policy head and the action draw of a rollout step as ONE kernel (uavagent_actor_head_f32)
         self.fused_head = bool(fused_head) and self.hip_gemms and 576 < self.net.n_action <= 640
         # overlap_dw (one rank, hip_gemms): the three dW GEMMs (MFMA bound, 1.6 ms at config 3) run on a side stream beside the
-        # first-layer table gradient (sort + indexed row sums: memory bound, 2.4 ms) instead of between the dX GEMMs
+        # first-layer table gradient (sort + indexed row sums: memory bound, 2.4 ms) instead of between the dX GEMMs.  Off by default:
+        # side by side each runs that much slower (rocprofv3: the gather 2.2 -> 3.2 ms, a dW GEMM 0.33 -> up to 2.1 ms); the update takes
+        # the same 6.9 ms either way (tools/ab_update.py)
         self.overlap_dw = bool(overlap_dw)
+        # early_sort (hip_gemms): the table gradient's sort of the (row, sample) pairs starts on a side stream before the update's forward pass
+        self.early_sort = bool(early_sort)
         # fused_obs: steps 1 .. T-1 of a rollout build their index list inside the first layer's kernel (uavagent_first_layer_from_obs_f32)
         # instead of a separate obs_indices launch after every env step
         self.fused_obs = bool(fused_obs) and env.nBS + env.nUE <= 64
@@ -604,7 +608,7 @@ class A2CRunner:
         hip = self.hip_gemms
         # The table gradient's sort needs only idx: on the side stream, beside the forward pass and the dX chain (hip path; one sort
         # serves both trunks' sums when they are exchanged separately).
-        early_sort = hip and self.overlap_dw and idx.is_contiguous()
+        early_sort = hip and self.early_sort and idx.is_contiguous()
         if early_sort:
             main = torch.cuda.current_stream(self.dev)
             if self._side is None:

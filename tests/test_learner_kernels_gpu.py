@@ -91,6 +91,25 @@ def test_rollout_with_index_lists_built_in_the_gather_is_the_same_rollout():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [{"overlap_dw": True}, {"early_sort": False}, {"overlap_dw": True, "early_sort": False}], ids=lambda k: "+".join(sorted(k)))
+def test_update_stream_variants_leave_the_same_parameters(kw):
+    """The update's optional side-stream forms (dW GEMMs beside the table gradient; the table gradient's sort before the forward pass)
+    run the same kernels on the same operands in another order of issue: parameters and RMSProp accumulators bit for bit."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv
+    from drl_uav_cellularnet_amd.agent import A2CRunner
+
+    outs = []
+    for k in ({}, kw):
+        env = BatchedMobiEnv(1024, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+        r = A2CRunner(env, rollout=40, **k)                            # 40 960 samples: the update's large-M kernels
+        for _ in range(2):
+            r.train_rollout()
+        assert r.stats["dw_on_side_stream"] == bool(k.get("overlap_dw", False))
+        outs.append((r.flat.w.clone(), r.flat.ms.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_sample_actions_kernel_is_the_inverse_cdf_draw():
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from drl_uav_cellularnet_amd import BatchedMobiEnv
 from drl_uav_cellularnet_amd.agent import A2CRunner
-variants = {"dw_on_side_stream": {}, "dw_in_line": {"overlap_dw": False}}
+variants = {"dw_on_side_stream": {"overlap_dw": True}, "dw_in_line": {}, "dw_in_line_no_early_sort": {"early_sort": False}}
 runners = {}
 for k, kw in variants.items():
     env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
@@ -15,7 +15,7 @@ for k, kw in variants.items():
     for _ in range(3):
         runners[k].train_rollout()
 ws = [r.flat.w for r in runners.values()]
-res = {"same_parameters_after_3_rollouts": bool(torch.equal(ws[0], ws[1])), "train_rollout_ms": {k: [] for k in variants},
+res = {"same_parameters_after_3_rollouts": bool(all(torch.equal(ws[0], w) for w in ws[1:])), "train_rollout_ms": {k: [] for k in variants},
        "update_ms": {k: [] for k in variants}, "stats": {k: {kk: vv for kk, vv in r.stats.items() if kk in ("dw_on_side_stream", "hip_gemms", "forward_reused")} for k, r in runners.items()}}
 for rnd in range(4):
     for k, r in runners.items():
