@@ -68,6 +68,14 @@ def test_agent_library_exports_its_header():
     assert flo(one, None, one, None, None, None, ctypes.c_void_p(18), one, one, 8, 20, 4, 100, 200, 50000, 1, None, None) == -1
     assert b"aligned" in lib.uavagent_last_error()
     assert flo(one, None, one, None, None, None, one, one, one, 0, 20, 4, 100, 200, 50000, 1, None, None) == 0     # no envs: no launch
+    # ABI 4: the table gradient's two halves check their arguments like the single call
+    big = ctypes.c_void_p(256)
+    assert lib.uavagent_rows_grad_sort(one, 100, 65, 400, 50000, big, 1 << 30, None) == -1                          # k > 64
+    assert lib.uavagent_rows_grad_sort(None, 100, 24, 400, 50000, big, 1 << 30, None) == -1 and b"null" in lib.uavagent_last_error()
+    assert lib.uavagent_rows_grad_sort(one, 100, 24, 400, 50000, ctypes.c_void_p(264), 1 << 30, None) == -1 and b"256-byte" in lib.uavagent_last_error()
+    assert lib.uavagent_rows_grad_sort(one, 1 << 27, 24, 400, 50000, big, 1 << 30, None) == -1 and b"32-bit" in lib.uavagent_last_error()
+    assert lib.uavagent_rows_grad_sums_f32(one, 100, 24, 202, 2, 50000, one, one, big, 1 << 30, None) == -1         # h % 4
+    assert lib.uavagent_rows_grad_sums_f32(one, 100, 24, 200, 2, 50000, one, None, big, 1 << 30, None) == -1        # two tables, one output
 
 
 def test_gemm_host_logic_without_gpu():
