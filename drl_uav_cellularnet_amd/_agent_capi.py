@@ -96,6 +96,20 @@ def _check(rc, what):
         raise UavAgentError("%s: %s" % (what, load().uavagent_last_error().decode()))
 
 
+def _same_device(what, *tensors):
+    """Every operand of one launch lives on one device (the launch goes to that device's current stream)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise UavAgentError("%s: every operand must be a CUDA tensor" % what)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise UavAgentError("%s: operands on different devices (%s and %s)" % (what, dev, t.device))
+
+
 def _f32c(t, what):
     if t is not None and (t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous()):
         raise UavAgentError("%s must be a contiguous float32 CUDA tensor" % what)
@@ -315,11 +329,24 @@ def gemm_rows(a, w, out, w_transposed=False, bias=None, relu6=False, relu6_mask_
         raise UavAgentError("gemm_rows: shapes do not agree: a %s, w %s (transposed=%s), out %s" % (tuple(a.shape), tuple(w.shape), w_transposed, tuple(out.shape)))
     if bias is not None:
         _f32c(bias, "bias")
+        if bias.numel() != N:
+            raise UavAgentError("gemm_rows: bias must have %d elements" % N)
+    if colsum_out is not None:
+        _f32c(colsum_out, "colsum_out")
+        if colsum_out.numel() != N:
+            raise UavAgentError("gemm_rows: colsum_out must have %d elements" % N)
     h = relu6_mask_h
-    _check(lib.uavagent_gemm_rows_f32(_ptr(a), _row_stride(a, "a"), _ptr(w), _row_stride(w, "w"), 1 if w_transposed else 0, M, K, N,
-                                      _ptr(bias), 1 if relu6 else 0, _ptr(h), 0 if h is None else _row_stride(h, "relu6_mask_h"),
-                                      _ptr(out), _row_stride(out, "out"), _ptr(colsum_out), _ptr(workspace),
-                                      0 if workspace is None else workspace.numel(), _stream(a.device)), "uavagent_gemm_rows_f32")
+    if h is not None and tuple(h.shape) != (M, N):
+        raise UavAgentError("gemm_rows: relu6_mask_h must be [%d, %d]" % (M, N))
+    if workspace is not None and (workspace.dtype != torch.uint8 or not workspace.is_cuda or not workspace.is_contiguous()):
+        raise UavAgentError("gemm_rows: workspace must be a contiguous uint8 CUDA tensor (gemm_rows_workspace)")
+    _same_device("gemm_rows", a, w, out, bias, h, colsum_out, workspace)
+    with torch.cuda.device(a.device):
+        rc = lib.uavagent_gemm_rows_f32(_ptr(a), _row_stride(a, "a"), _ptr(w), _row_stride(w, "w"), 1 if w_transposed else 0, M, K, N,
+                                        _ptr(bias), 1 if relu6 else 0, _ptr(h), 0 if h is None else _row_stride(h, "relu6_mask_h"),
+                                        _ptr(out), _row_stride(out, "out"), _ptr(colsum_out), _ptr(workspace),
+                                        0 if workspace is None else workspace.numel(), _stream(a.device))
+    _check(rc, "uavagent_gemm_rows_f32")
     return out
 
 
@@ -333,9 +360,14 @@ def actor_head(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2_out, 
         raise UavAgentError("actor_head: shapes do not agree")
     if actions_out.dtype != torch.int64 or actions_out.numel() != N or uniforms.numel() != N or logits_pad_out.shape[0] != N:
         raise UavAgentError("actor_head: one uniform, one logits row and one int64 action per row of h1")
-    _check(load().uavagent_actor_head_f32(_ptr(h1), _ptr(w2t), _ptr(b2), _ptr(w3t_padded), _ptr(b3_padded), _ptr(uniforms), N, H, int(n_actions),
-                                          _ptr(h2_out), _ptr(logits_pad_out), _row_stride(logits_pad_out, "logits_pad_out"), _ptr(actions_out),
-                                          _stream(h1.device)), "uavagent_actor_head_f32")
+    if b2.numel() != H:
+        raise UavAgentError("actor_head: b2 must have %d elements" % H)
+    _same_device("actor_head", h1, w2t, b2, w3t_padded, b3_padded, uniforms, h2_out, logits_pad_out, actions_out)
+    with torch.cuda.device(h1.device):
+        rc = load().uavagent_actor_head_f32(_ptr(h1), _ptr(w2t), _ptr(b2), _ptr(w3t_padded), _ptr(b3_padded), _ptr(uniforms), N, H, int(n_actions),
+                                            _ptr(h2_out), _ptr(logits_pad_out), _row_stride(logits_pad_out, "logits_pad_out"), _ptr(actions_out),
+                                            _stream(h1.device))
+    _check(rc, "uavagent_actor_head_f32")
     return actions_out
 
 
@@ -357,8 +389,13 @@ def gemm_tn(a, b, out, workspace, dbias_out=None):
         _f32c(dbias_out, "dbias_out")
         if dbias_out.numel() != J:
             raise UavAgentError("gemm_tn: dbias_out must have %d elements" % J)
-    _check(lib.uavagent_gemm_tn_f32(_ptr(a), _ptr(b), M, I, J, _row_stride(b, "b"), _ptr(out), _row_stride(out, "out"), _ptr(dbias_out),
-                                    _ptr(workspace), workspace.numel(), _stream(a.device)), "uavagent_gemm_tn_f32")
+    if workspace is None or workspace.dtype != torch.uint8 or not workspace.is_cuda or not workspace.is_contiguous():
+        raise UavAgentError("gemm_tn: workspace must be a contiguous uint8 CUDA tensor (gemm_tn_workspace)")
+    _same_device("gemm_tn", a, b, out, dbias_out, workspace)
+    with torch.cuda.device(a.device):
+        rc = lib.uavagent_gemm_tn_f32(_ptr(a), _ptr(b), M, I, J, _row_stride(b, "b"), _ptr(out), _row_stride(out, "out"), _ptr(dbias_out),
+                                      _ptr(workspace), workspace.numel(), _stream(a.device))
+    _check(rc, "uavagent_gemm_tn_f32")
     return out
 
 

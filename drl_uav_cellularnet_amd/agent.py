@@ -207,19 +207,38 @@ _TUNABLE_DIR = None
 
 
 def freeze_gemm_tuning():
-    """Stop TunableOp from TUNING further shapes (the picks already made or loaded stay in use): called by A2CRunner after its
-    eager warm-up pass, so that no later GEMM of the host application -- or of a graph capture -- triggers a timing run, and two
-    processes that warmed up on the same shapes keep the same picks."""
+    """Stop TunableOp from TUNING further shapes (the picks already made or loaded stay in use): called by A2CRunner.train_rollout
+    after its first rollout + update, so that no later GEMM of the host application -- or of a graph capture -- triggers a timing
+    run, and two processes that warmed up on the same shapes keep the same picks.  Returns True when tuning was on and is now off."""
     if _TUNABLE_DONE:
         import torch.cuda.tunable as tun
 
         tun.tuning_enable(False)
+        return True
+    return False
+
+
+def gemm_tuning_is_active():
+    """True while TunableOp may still start timing runs for new shapes (enable_gemm_tuning() called, freeze_gemm_tuning() not yet)."""
+    if not _TUNABLE_DONE:
+        return False
+    import torch.cuda.tunable as tun
+
+    return bool(tun.tuning_is_enabled())
 
 
 def _remove_tunable_dir():
     import shutil
 
     if _TUNABLE_DIR:
+        try:                                  # TunableOp rewrites its results file when the process ends, after this handler:
+            import os                         # point it away from the directory that is about to disappear
+
+            import torch.cuda.tunable as tun
+
+            tun.set_filename(os.devnull)
+        except Exception:
+            pass
         shutil.rmtree(_TUNABLE_DIR, ignore_errors=True)
 
 
@@ -388,6 +407,7 @@ class A2CRunner:
         self.stats = {}
         self._graph = None
         self._upd = None
+        self._tuning_frozen = False
 
     def _ms_view(self, key):
         p = getattr(self.net, key)
@@ -638,10 +658,9 @@ class A2CRunner:
                 torch.addmm(net.a_b3, b["h2a"], net.a_w3, out=b["logits"])
         self._fwd_valid = False                                        # the backward pass below overwrites logits and h2a
         if hip:
-            if reuse:                                  # (collect() refreshed the transposed copies from these very weights)
-                A.gemm_rows(b["h1c"], self._wt["c_w2t"], b["h2c"], w_transposed=True, bias=net.c_b2, relu6=True)
-            else:
-                A.gemm_rows(b["h1c"], net.c_w2, b["h2c"], bias=net.c_b2, relu6=True)
+            # one arithmetic whether or not the rollout's forward pass is reused: W2^T through the k-contiguous kernels (collect() /
+            # the branch above refreshed the transposed copies from these very weights)
+            A.gemm_rows(b["h1c"], self._wt["c_w2t"], b["h2c"], w_transposed=True, bias=net.c_b2, relu6=True)
         else:
             torch.addmm(net.c_b2, b["h1c"], net.c_w2, out=b["h2c"]).clamp_(0.0, 6.0)
         A.rowdot(b["h2c"], net.c_w3, net.c_b3, b["v"])
@@ -778,7 +797,13 @@ class A2CRunner:
         return self.stats
 
     def train_rollout(self):
-        return self.update(*self.collect())
+        stats = self.update(*self.collect())
+        if self.gemm_tuning and not self._tuning_frozen:
+            # every GEMM shape of a rollout + update has now run once eagerly: no timing run may start later (inside a training loop, a
+            # graph capture of the host application, or with another pick in another process)
+            freeze_gemm_tuning()
+            self._tuning_frozen = True
+        return stats
 
     # ---- checkpoint / resume (the reference saves the actor only and cannot resume) -------------------------------
     def state_dict(self):

@@ -260,6 +260,14 @@ class BatchedMobiEnv:
             setattr(st, k + "_dev", out[k].data_ptr())
         return st
 
+    def device_error(self):
+        """Sticky device-side error word of the handle (uavenv_device_error): 0, or the code a kernel left when it gave up waiting for
+        a hand-off of a one-launch rotation schedule.  Meaningful after the launch's stream has been synchronised; while it is
+        non-zero every call on this env raises UavEnvError (UAVENV_E_DEVICE) until set_state() installs a whole state again."""
+        code = C.c_uint32(0)
+        _capi.check(self._lib.uavenv_device_error(self._h, C.byref(code)))
+        return int(code.value)
+
     def step_many(self, actions, out=None, refresh_out=True):
         """T consecutive step() calls in ONE launch (uavenv_step_many) for actions that do not depend on the observations in
         between: ``actions`` int64 [T, N] on this device.  Returns a dict of [T, ...] tensors (block t = what step t returned;

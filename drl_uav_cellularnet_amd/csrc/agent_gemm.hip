@@ -15,6 +15,7 @@
 // Fragment maps used below (cdna_hip_programming.md section 3): lane l = (r = l & 15, q = l >> 4);
 //   A operand = A[row r][k = q],  B operand = B[k = q][col r],  accumulator register t = C[row 4 q + t][col r].
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -1587,6 +1588,19 @@ extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
     return b;
 }
 
+// CU count of the CURRENT device (the caller has made the operands' device current), read once per device ordinal.
+static int cu_count_of_current_device() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 2) v = 256;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // UAVAGENT_ROWS_RESIDENT=0 (read once): the update's K = 200 GEMMs on version 4's 128-row workgroups instead of the resident-W kernel (A/B runs)
 static const bool g_rows_resident = [] { const char *e = getenv("UAVAGENT_ROWS_RESIDENT"); return e ? e[0] != '0' : true; }();
 
@@ -1637,7 +1651,7 @@ extern "C" int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *
     } while (0)
     if (w_transposed && vec && k == kRsK && n > kRsNBA * 16 && n <= 208 && m_rows > 32768 && g_rows_resident) {
         // W^T resident in LDS, persistent workgroups (gemm_rows_resident_kernel): the update's 200-wide layers
-        static const int n_cu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 2) v = 256; return v; }();
+        const int n_cu = cu_count_of_current_device();          // per device: a process may drive several
         const int nA = (n_cu * kRsNBA + (kRsNBA + kRsNBB) / 2) / (kRsNBA + kRsNBB) < n_cu ? (n_cu * kRsNBA + (kRsNBA + kRsNBB) / 2) / (kRsNBA + kRsNBB) : n_cu - 1;
         if (colp && hipMemsetAsync(colp, 0, (size_t)nA * kNP * sizeof(float), st) != hipSuccess) return fail3(UAVAGENT_E_HIP, "gemm_rows: memset failed");
         const dim3 g2((unsigned)n_cu), b2(kRsThr);

@@ -35,10 +35,16 @@ struct uavenv {
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
     const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
-    struct RotPlan { int n_steps; int n_launches; long long slots; int4 *dev; };   // rotation schedules built so far (one per n_steps)
+    struct RotPlan { int n_steps; int n_launches; long long slots; int4 *dev; };   // rotation schedules built so far (one per n_steps;
+                                                                                  // n_launches 0 = none applies: plain launch)
     std::vector<RotPlan> *rot_plans;
-    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 whenever a schedule exists (tests)
+    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 the one-launch schedule whenever one exists
+                        // (tests), 2 the several-launch schedule of round 3 whenever one exists (A/B runs)
     long long rot_slots;  // UAVENV_ROTATE_SLOTS (tests: pretend the device has this many SIMDs), else n_simd
+    uint32_t *sched_flag_dev;   // [env-wavefronts] hand-off words of the one-launch schedule (zero between calls)
+    uint32_t *err_host, *err_dev;   // sticky device-side error word: host-mapped memory, so that every entry point can test it without a HIP call
+    uint32_t spin_us;   // hand-off spin budget (UAVENV_HANDOFF_SPIN_US, default 2 s)
+    int drop_publish;   // UAVENV_DEBUG_DROP_PUBLISH=1 (test hook): schedules are built WITHOUT their publish bits, so every hand-off times out
     char *scratch_out;  // multi-pass handles, uavenv_step_many_packed: one step's nine output arrays (allocated on first use)
     int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
@@ -70,6 +76,24 @@ struct DeviceGuard {
         if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
     }
 };
+
+// A kernel that gave up on a hand-off (uavenv_kernels.h: sched_hand_off_wait) leaves a word in host-mapped memory.  The handle's state
+// is then incomplete: every later call on it fails until uavenv_set_state() installs a whole state again.
+static int poisoned(const uavenv *h, const char *what) {
+    if (h->err_host && *(volatile uint32_t *)h->err_host != 0u) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "%s: an earlier multi-step launch on this handle failed on the device (code 0x%08x: a hand-off between two "
+                      "wavefronts timed out); its state is incomplete -- uavenv_set_state() or a new handle", what, *(volatile uint32_t *)h->err_host);
+        return fail(UAVENV_E_DEVICE, buf);
+    }
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_device_error(uavenv_t *h, uint32_t *code) {
+    if (!h || !code) return fail(UAVENV_E_INVALID, "device_error: null argument");
+    *code = h->err_host ? *(volatile uint32_t *)h->err_host : 0u;
+    return UAVENV_OK;
+}
 
 extern "C" int uavenv_abi_version(void) { return UAVENV_ABI_VERSION; }
 extern "C" const char *uavenv_last_error(void) { return g_err.c_str(); }
@@ -168,8 +192,11 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     h->force_pin = -1;
     if (const char *f = std::getenv("UAVENV_FORCE_PIN")) h->force_pin = (f[0] == '1') ? 1 : 0;
     h->rotate = -1;
-    if (const char *f = std::getenv("UAVENV_ROTATE")) h->rotate = (f[0] == '1') ? 1 : 0;
+    if (const char *f = std::getenv("UAVENV_ROTATE")) h->rotate = (f[0] == '1') ? 1 : (f[0] == '2') ? 2 : 0;
     h->rot_plans = new (std::nothrow) std::vector<uavenv::RotPlan>();
+    h->spin_us = 2000000u;
+    if (const char *f = std::getenv("UAVENV_HANDOFF_SPIN_US")) { const long long v = std::atoll(f); if (v > 0 && v < 60000000ll) h->spin_us = (uint32_t)v; }
+    if (const char *f = std::getenv("UAVENV_DEBUG_DROP_PUBLISH")) h->drop_publish = (f[0] == '1') ? 1 : 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
@@ -218,6 +245,14 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
         return bail(UAVENV_E_HIP, "hipMemcpy bs_init", e);
     if ((e = hipMemcpy(h->act_pow_dev, act_pow, sizeof(act_pow), hipMemcpyHostToDevice)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemcpy act_pow", e);
     if ((e = hipMemcpy(h->gid_dev, gid.data(), n_gid, hipMemcpyHostToDevice)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemcpy gid table", e);
+    {   // one-launch schedules (rotation_plan): one hand-off word per env-wavefront, and the sticky error word in host-mapped memory
+        const size_t n_flag = (size_t)n_envs + 64;           // (>= env-wavefronts for any envs-per-wavefront)
+        if ((e = hipMalloc((void **)&h->sched_flag_dev, n_flag * sizeof(uint32_t))) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc hand-off words", e);
+        if ((e = hipMemset(h->sched_flag_dev, 0, n_flag * sizeof(uint32_t))) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemset hand-off words", e);
+        if ((e = hipHostMalloc((void **)&h->err_host, 64, hipHostMallocMapped)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipHostMalloc error word", e);
+        std::memset(h->err_host, 0, 64);
+        if ((e = hipHostGetDevicePointer((void **)&h->err_dev, h->err_host, 0)) != hipSuccess) return bail(UAVENV_E_HIP, "hipHostGetDevicePointer error word", e);
+    }
 
     KParams &k = h->kp;
     std::memset(&k, 0, sizeof(k));
@@ -253,6 +288,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.bs_init = h->bs_init_dev;
     k.act_pow = h->act_pow_dev;
     k.gid_of_u = h->gid_dev;
+    k.sched_flag = h->sched_flag_dev; k.sched_err = h->err_dev; k.sched_spin_us = h->spin_us;
     u32div_gen((uint32_t)cfg->n_act, &k.div_magic, &k.div_shift);   // exact digit extraction (intdiv.h)
     k.act32 = (n_joint <= 0xFFFFFFFFll) ? 1 : 0;  // 32-bit digit extraction when every joint action fits
     // Packed kernel: floor(64/U) env instances per wavefront; needs the group / UAV owner lanes inside a slot.
@@ -275,6 +311,8 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
     if (h->scratch_out) (void)hipFree(h->scratch_out);
+    if (h->sched_flag_dev) (void)hipFree(h->sched_flag_dev);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     if (h->rot_plans) {
         for (auto &pl : *h->rot_plans) (void)hipFree(pl.dev);
         delete h->rot_plans;
@@ -410,7 +448,8 @@ static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s, long long la
     bool pin = fast && (waves >= h->n_simd) && (waves <= 2 * h->n_simd);
     // Multi-step launches: the pinned loop wins below one wavefront per SIMD too (1536 envs: 3.47 us per step unpinned; the lone-wave
     // argument above is about materialising constants once per LAUNCH, which a 100-step launch amortises).
-    if (MANY) pin = fast && (waves <= 2 * h->n_simd);
+    // (a rotation schedule launches S = k x SIMDs slots for its W > S env-wavefronts: the wavefronts that are resident count)
+    if (MANY) pin = fast && ((launch_waves > 0 ? launch_waves : waves) <= 2 * h->n_simd);
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
@@ -469,6 +508,7 @@ extern "C" int uavenv_warmup(uavenv_t *h, int n_ticks, const UavEnvInject *inj, 
     if (inj && (inj->theta_u_dev || inj->group_u_dev) && n_ticks != 1)
         return fail(UAVENV_E_INVALID, "warmup: injected draws cover exactly one tick");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "warmup")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, inj, nullptr);
     p.n_ticks = n_ticks;
@@ -479,6 +519,7 @@ extern "C" int uavenv_reset(uavenv_t *h, const uint8_t *mask_dev, const UavEnvIn
                             void *stream) {
     if (!h) return fail(UAVENV_E_INVALID, "reset: null handle");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "reset")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, inj, out);
     p.mask = mask_dev; p.n_ticks = 1;
@@ -489,6 +530,7 @@ extern "C" int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnv
                            void *stream) {
     if (!h || !actions_dev) return fail(UAVENV_E_INVALID, "step: null handle or actions");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, inj, out);
     p.actions = (const long long *)actions_dev; p.n_ticks = 1;
@@ -514,39 +556,55 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
 }
 
 // ---- rotation schedule for multi-step launches ----------------------------------------------------------------------------------
-// A batch of W env-wavefronts on S SIMDs with S < W < 2 S leaves W - S SIMDs with two wavefronts for the whole launch; they set its
-// time and the others idle half of it (BASELINE's 4096 envs x 20 UEs: 1366 wavefronts on 1024 SIMDs).  The W x T wavefront-steps fit
-// S slots in M = ceil(W T / S) step-times (McNaughton's wrap-around rule: fill slot after slot, a job that does not fit is split, its
-// LAST steps at the end of this slot, its FIRST steps at the start of the next).  Cutting every slot's timeline at D = ceil(M / (M - T))
-// common boundaries gives D launches of S wavefronts, one per SIMD, each working through at most two segments (env-wavefront, first
-// step, steps); a split job's two parts are at least M - T step-times apart, hence in different launches, so stream order is all the
-// synchronisation needed.  Measured bound before building it (profiles/r03a_many_ab_rotation_bound.json): 4 launches of 1024
-// wavefronts x 34 steps take 396 us against 431 us for 1366 wavefronts x 100 steps.
-// Returns the cached / newly built plan, or nullptr when rotation does not apply (then the plain launch runs).
+// A batch of W env-wavefronts on S slots (S = k x SIMDs, k = floor(W / SIMDs) wavefronts resident per SIMD) with S < W < 2 S leaves
+// W - S SIMDs with one wavefront more than the others for the whole launch; they set its time and the others idle part of it
+// (BASELINE's 4096 envs x 20 UEs: 1366 wavefronts on 1024 SIMDs).  The W x T wavefront-steps fit S slots in M = ceil(W T / S)
+// step-times (McNaughton's wrap-around rule: fill slot after slot; a job that does not fit is split, its LAST steps at the end of this
+// slot, its FIRST steps at the start of the next).  M < 2 T, so a slot holds at most three pieces: [first steps of a split job]
+// [one whole job] [last steps of another split job].
+//   form 1 (round 4, the default): ONE launch of S persistent wavefronts.  The wavefront that ran a job's first steps stores the
+//     state, releases and sets the job's flag; the wavefront that runs its last steps polls the flag (bounded), acquires and loads
+//     (uavenv_kernels.h: sched_hand_off_*).  The publishing piece is the FIRST piece of its slot and waits for nothing, and the
+//     waiting piece starts M - T step-times after the publishing one ended, so in practice nobody waits.
+//   form 2 (round 3, kept for A/B runs, UAVENV_ROTATE=2): the slots' timelines cut at D = ceil(M / (M - T)) common boundaries give D
+//     launches; a split job's two parts are at least M - T step-times apart, hence in different launches, and stream order is the
+//     synchronisation.  Each launch costs the ~8 us of load / store / launch phases a launch has: it paid from 48 steps on only.
+// Returns the index of the cached / newly built plan in h->rot_plans, or -1 when no schedule applies (then the plain launch runs).
 static long long rot_padded_slots(long long S) { return (S + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock; }
-static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
-    // Automatic use from 48 steps per call on: each of the D ~ 4 launches of a schedule costs the ~8 us of load / store / launch phases a
-    // launch has, against ~0.6 us gained per step (4.31 T + 8 us plain, 3.70 T + 8 D us rotated: break-even near T = 39; a 20-step call
-    // measured 5.8e8 env-steps/s rotated against 6.7e8 plain, profiles/r03r_*).
-    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < (h->rotate == 1 ? 2 : 48)) return nullptr;
-    const long long W = (h->N + h->kp.epw - 1) / h->kp.epw, S = h->rot_slots;
-    if (W <= S || W >= 2 * S) return nullptr;
-    for (const auto &pl : *h->rot_plans) if (pl.n_steps == T) return pl.dev ? &pl : nullptr;
-    auto remember = [&](int D, int4 *dev) -> const uavenv::RotPlan * {
+static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
+    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < 2) return -1;
+    const long long W = (h->N + h->kp.epw - 1) / h->kp.epw;
+    const long long k_res = W / h->rot_slots;                      // wavefronts every SIMD hosts for the whole launch
+    const long long S = k_res * h->rot_slots;
+    if (k_res < 1 || W <= S) return -1;                            // fewer wavefronts than SIMDs, or a balanced batch
+    for (size_t i = 0; i < h->rot_plans->size(); ++i)
+        if ((*h->rot_plans)[i].n_steps == T) return (*h->rot_plans)[i].dev ? (int)i : -1;
+    // A new schedule needs a hipMalloc and a synchronous upload: not inside a stream capture (the plain launch runs instead, and the
+    // call is not remembered, so that a later call outside the capture builds it), cf. uavenv_step_many_prepare.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (cap != hipStreamCaptureStatusNone) return -1;
+    auto remember = [&](int D, int4 *dev) -> int {
         h->rot_plans->push_back(uavenv::RotPlan{T, D, S, dev});
-        return dev ? &h->rot_plans->back() : nullptr;
+        return dev ? (int)h->rot_plans->size() - 1 : -1;
     };
     const long long M = (W * T + S - 1) / S;                       // makespan in step-times
-    if (M - T < 1) return remember(0, nullptr);
-    const long long D = (M + (M - T) - 1) / (M - T);              // launches: windows no longer than M - T
-    // Automatic use only where it pays: a single wavefront per SIMD runs a step in ~0.64 of the time two co-resident ones take
-    // (2.77 vs 4.31 us at 4096 envs), every extra launch costs ~8 us of load / store / launch phases: 1.2 <= W / S <= 1.45.
-    if (h->rotate != 1 && (D > 6 || 100 * W > 145 * S)) return remember(0, nullptr);
-    if (D > 64) return remember(0, nullptr);
+    if (M - T < 1 || M >= 2 * (long long)T) return remember(0, nullptr);
+    const bool one_launch = h->rotate != 2;
+    // Automatic use only where it pays.  One wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take
+    // (2.77 vs 4.31 us at 4096 envs), and the pinned kernel keeps at most two wavefronts resident per SIMD: k <= 2, W / S <= 1.45.
+    // A hand-off costs its two wavefronts a state store + release and a poll + acquire + state load (~10 us together, measured),
+    // against ~0.6 us gained per step: from 16 steps per call on.
+    if (h->rotate == -1 && (k_res > 2 || 100 * W > 145 * S || T < 16)) return remember(0, nullptr);
+    long long D = 1;
+    if (!one_launch) {
+        D = (M + (M - T) - 1) / (M - T);                           // launches: windows no longer than M - T
+        if (D > 64) return remember(0, nullptr);
+    }
     std::vector<long long> bound((size_t)D + 1);
     for (long long k = 0; k <= D; ++k) bound[(size_t)k] = k * M / D;
-    struct Piece { int ew, t0, nt; };
-    std::vector<std::vector<Piece>> cell((size_t)(D * S));        // [launch][slot] -> pieces in time order
+    struct Piece { int ew, t0, nt; long long time; };
+    std::vector<std::vector<Piece>> cell((size_t)(D * S));        // [launch][slot] -> pieces
     std::vector<int> last_launch((size_t)W, -1), next_step((size_t)W, 0);
     bool ok = true;
     auto place = [&](long long slot, long long time, int ew, int step, int len) {   // a run of `len` steps of job ew at `time` on `slot`
@@ -554,11 +612,11 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
             long long k = 0;
             while (bound[(size_t)k + 1] <= time) ++k;                               // window of `time`
             const int n = (int)std::min<long long>(len, bound[(size_t)k + 1] - time);
-            cell[(size_t)(k * S + slot)].push_back(Piece{ew, step, n});
+            cell[(size_t)(k * S + slot)].push_back(Piece{ew, step, n, time});
             time += n; step += n; len -= n;
         }
     };
-    {   // McNaughton fill.  The FIRST steps of a split job go to the next slot's start, so jobs are placed in two passes per slot.
+    {   // McNaughton fill.  The FIRST steps of a split job go to the next slot's start.
         long long slot = 0, t = 0;
         for (long long j = 0; j < W && ok; ++j) {
             if (slot >= S) { ok = false; break; }
@@ -575,17 +633,38 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
             }
         }
     }
-    // Verify what the argument above promises: every job's steps 0..T-1 exactly once, in launches that strictly increase with the
-    // step index; at most two pieces per (launch, slot).
+    for (auto &c : cell) std::sort(c.begin(), c.end(), [](const Piece &x, const Piece &y) { return x.time < y.time; });
+    // Verify what the argument above promises.  Both forms: every job's steps 0..T-1 exactly once, at most kSchedPieces pieces per
+    // (launch, slot).  Form 2: a job's pieces in launches that strictly increase with the step index.  Form 1: a job is one whole piece,
+    // or two pieces on different slots of which the first one (the one that publishes) LEADS its slot: it can never wait, so every
+    // wait ends -- no deadlock whatever the order in which the hardware starts the wavefronts.
+    struct Seen { int n, slot0, q0, len0, slot1, t1, len1; };
+    std::vector<Seen> seen((size_t)W, Seen{0, -1, -1, 0, -1, 0, 0});
     for (long long k = 0; k < D && ok; ++k)
         for (long long sl = 0; sl < S && ok; ++sl) {
             const auto &c = cell[(size_t)(k * S + sl)];
-            if (c.size() > 2) ok = false;
-            for (const Piece &pc : c) {
-                if (pc.t0 != next_step[(size_t)pc.ew] || (int)k <= last_launch[(size_t)pc.ew]) { ok = false; break; }
-                next_step[(size_t)pc.ew] = pc.t0 + pc.nt;
-                last_launch[(size_t)pc.ew] = (int)k;
+            if (c.size() > (size_t)kSchedPieces) ok = false;
+            for (size_t q = 0; q < c.size() && ok; ++q) {
+                const Piece &pc = c[q];
+                if (one_launch) {
+                    Seen &z = seen[(size_t)pc.ew];
+                    if (pc.t0 == 0) { z.slot0 = (int)sl; z.q0 = (int)q; z.len0 = pc.nt; }
+                    else { z.slot1 = (int)sl; z.t1 = pc.t0; z.len1 = pc.nt; }
+                    z.n += 1;
+                    next_step[(size_t)pc.ew] += pc.nt;
+                } else {
+                    if (pc.t0 != next_step[(size_t)pc.ew] || (int)k <= last_launch[(size_t)pc.ew]) { ok = false; break; }
+                    next_step[(size_t)pc.ew] = pc.t0 + pc.nt;
+                    last_launch[(size_t)pc.ew] = (int)k;
+                }
             }
+        }
+    if (one_launch)
+        for (long long j = 0; j < W && ok; ++j) {
+            const Seen &z = seen[(size_t)j];
+            if (z.n == 1) ok = z.slot0 >= 0 && z.len0 == T;
+            else if (z.n == 2) ok = z.slot0 >= 0 && z.slot1 >= 0 && z.slot0 != z.slot1 && z.q0 == 0 && z.len0 >= 1 && z.t1 == z.len0 && z.len0 + z.len1 == T;
+            else ok = false;
         }
     for (long long j = 0; j < W && ok; ++j) if (next_step[(size_t)j] != T) ok = false;
     if (!ok) return remember(0, nullptr);
@@ -593,11 +672,18 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
     // wavefronts past slot S - 1 of the last one read rows too -- theirs are all-zero (no steps).  (Round 3, first GPU run: with rows
     // per slot those wavefronts read the next launch's rows, or past the allocation for the last launch: a memory fault at S = 26.)
     const long long Sp = rot_padded_slots(S);
-    std::vector<int4> table((size_t)(D * Sp * 2), int4{0, 0, 0, 0});
+    std::vector<int4> table((size_t)(D * Sp * kSchedPieces), int4{0, 0, 0, 0});
     for (long long k = 0; k < D; ++k)
         for (long long sl = 0; sl < S; ++sl) {
             const auto &c = cell[(size_t)(k * S + sl)];
-            for (size_t q = 0; q < c.size(); ++q) table[(size_t)(k * Sp + sl) * 2 + q] = int4{c[q].ew, c[q].t0, c[q].nt, 0};
+            for (size_t q = 0; q < c.size(); ++q) {
+                int bits = 0;
+                if (one_launch) {
+                    if (c[q].t0 > 0) bits |= SCHED_WAIT;
+                    if (c[q].t0 + c[q].nt < T && !h->drop_publish) bits |= SCHED_PUBLISH;
+                }
+                table[(size_t)((k * Sp + sl) * kSchedPieces) + q] = int4{c[q].ew, c[q].t0, c[q].nt, bits};
+            }
         }
     int4 *dev = nullptr;
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
@@ -608,7 +694,7 @@ static const uavenv::RotPlan *rotation_plan(uavenv_t *h, int T) {
 extern "C" int uavenv_step_many_prepare(uavenv_t *h, int n_steps) {
     if (!h || n_steps < 0) return fail(UAVENV_E_INVALID, "step_many_prepare: null handle or negative n_steps");
     DeviceGuard guard(h->device);
-    (void)rotation_plan(h, n_steps);      // builds + uploads + caches the schedule when one applies
+    (void)rotation_plan(h, n_steps, nullptr);      // builds + uploads + caches the schedule when one applies
     return UAVENV_OK;
 }
 
@@ -616,18 +702,20 @@ extern "C" int uavenv_step_many_prepare(uavenv_t *h, int n_steps) {
 extern "C" int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots) {
     if (!h || n_steps < 0) return fail(UAVENV_E_INVALID, "debug_rotation_info: null handle or negative n_steps");
     DeviceGuard guard(h->device);
-    const uavenv::RotPlan *pl = rotation_plan(h, n_steps);
-    if (n_launches) *n_launches = pl ? pl->n_launches : 0;
-    if (slots) *slots = pl ? pl->slots : 0;
+    const int i = rotation_plan(h, n_steps, nullptr);
+    if (n_launches) *n_launches = i >= 0 ? (*h->rot_plans)[(size_t)i].n_launches : 0;
+    if (slots) *slots = i >= 0 ? (*h->rot_plans)[(size_t)i].slots : 0;
     return UAVENV_OK;
 }
 
 template <int MANY_>
 static int launch_many(uavenv_t *h, KParams &p, int n_steps, hipStream_t s) {
-    if (const uavenv::RotPlan *pl = rotation_plan(h, n_steps)) {       // (first use of this n_steps: builds + uploads the table, synchronously)
-        for (int k = 0; k < pl->n_launches; ++k) {
-            p.sched = pl->dev + (size_t)k * (size_t)rot_padded_slots(pl->slots) * 2;
-            if (int rc = launch_env<MODE_STEP, MANY_>(h, p, s, pl->slots)) return rc;
+    const int i = rotation_plan(h, n_steps, s);        // (first use of this n_steps outside a capture: builds + uploads the table, synchronously)
+    if (i >= 0) {
+        const uavenv::RotPlan pl = (*h->rot_plans)[(size_t)i];
+        for (int k = 0; k < pl.n_launches; ++k) {
+            p.sched = pl.dev + (size_t)k * (size_t)rot_padded_slots(pl.slots) * kSchedPieces;
+            if (int rc = launch_env<MODE_STEP, MANY_>(h, p, s, pl.slots)) return rc;
         }
         return UAVENV_OK;
     }
@@ -639,6 +727,7 @@ extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_s
     if (!h || !actions_dev || n_steps < 0) return fail(UAVENV_E_INVALID, "step_many: null handle / actions or negative n_steps");
     if (n_steps == 0) return UAVENV_OK;
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step_many")) return rc_dev;
     if (h->packed) {   // one launch: state stays in registers across the steps (env_kernel_packed<..., MANY = true>)
         KParams p = h->kp;
         fill_call(p, nullptr, out);
@@ -660,6 +749,7 @@ extern "C" int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_s
 extern "C" int uavenv_step_seq(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream) {
     if (!h || !actions_dev || n_steps < 0) return fail(UAVENV_E_INVALID, "step_seq: null handle / actions or negative n_steps");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step_seq")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, nullptr, out);
     p.n_ticks = 1;
@@ -701,6 +791,7 @@ extern "C" int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, 
         return fail(UAVENV_E_INVALID, "step_many_packed: null handle / actions / output record array, or negative n_steps");
     if (n_steps == 0) return UAVENV_OK;
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step_many_packed")) return rc_dev;
     const long long N = h->N, U = h->cfg.n_ue, B = h->cfg.n_bs;
     if (h->packed) {
         KParams p = h->kp;
@@ -747,6 +838,7 @@ extern "C" int uavenv_step_trace(uavenv_t *h, const int64_t *actions_dev, const 
                                  const UavEnvInject *inj, const UavEnvOut *out, void *stream) {
     if (!h || !actions_dev || !ue_xy_in_dev) return fail(UAVENV_E_INVALID, "step_trace: null handle, actions or trace");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step_trace")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, inj, out);
     p.actions = (const long long *)actions_dev; p.trace_xy = ue_xy_in_dev; p.n_ticks = 1;
@@ -757,6 +849,7 @@ extern "C" int uavenv_reset_trace(uavenv_t *h, const uint8_t *mask_dev, const in
                                   const UavEnvInject *inj, const UavEnvOut *out, void *stream) {
     if (!h || !ue_xy_in_dev) return fail(UAVENV_E_INVALID, "reset_trace: null handle or trace");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "reset_trace")) return rc_dev;
     KParams p = h->kp;
     fill_call(p, inj, out);
     p.mask = mask_dev; p.trace_xy = ue_xy_in_dev; p.n_ticks = 1;
@@ -773,6 +866,7 @@ static int ensure_obs_prev(uavenv_t *h) {
 extern "C" int uavenv_obs_dense(uavenv_t *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return fail(UAVENV_E_INVALID, "obs_dense: null handle or buffer");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "obs_dense")) return rc_dev;
     if (int rc = ensure_obs_prev(h)) return rc;   // (first call only; not inside a captured region)
     const KParams &k = h->kp;
     const size_t bytes = (size_t)k.N * (k.B + 1) * k.G * k.G * sizeof(float);
@@ -791,6 +885,7 @@ extern "C" int uavenv_obs_dense_update(uavenv_t *h, float *obs_dev, void *stream
         return fail(UAVENV_E_INVALID, "obs_dense_update: obs_dev is not the buffer the last uavenv_obs_dense call of this handle wrote; "
                                       "call uavenv_obs_dense on it first");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "obs_dense_update")) return rc_dev;
     const KParams &k = h->kp;
     const long long total = k.N * (k.U + k.B);
     hipLaunchKernelGGL((obs_cells_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -803,6 +898,7 @@ extern "C" int uavenv_sinr_area_at(uavenv_t *h, const int32_t *bs_xy_dev, const 
                                    double *out_f64_dev, void *stream) {
     if (!h || (!out_f32_dev && !out_f64_dev)) return fail(UAVENV_E_INVALID, "sinr_area: null handle or no output buffer");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "sinr_area_at")) return rc_dev;
     const KParams &k = h->kp;
     const int32_t *cells = bs_xy_dev ? bs_xy_dev : k.bs_xy;   // GetSinrInArea(bsLoc) takes ANY bsLoc (channel.py:411); NULL = the state's
     const size_t n = (size_t)k.N * k.G * k.G;
@@ -881,6 +977,7 @@ extern "C" int uavenv_state_layout(const uavenv_t *h, UavEnvStateLayout *layout)
 extern "C" int uavenv_get_state(uavenv_t *h, void *dst, int dst_is_device, void *stream) {
     if (!h || !dst) return fail(UAVENV_E_INVALID, "get_state: null argument");
     DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "get_state")) return rc_dev;
     HIP_TRY(hipMemcpyAsync(dst, h->blob, h->lay.total_bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            (hipStream_t)stream));
     if (!dst_is_device) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -893,5 +990,9 @@ extern "C" int uavenv_set_state(uavenv_t *h, const void *src, int src_is_device,
     HIP_TRY(hipMemcpyAsync(h->blob, src, h->lay.total_bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            (hipStream_t)stream));
     if (!src_is_device) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h->err_host && *(volatile uint32_t *)h->err_host != 0u) {   // a whole state again: the handle is usable (uavenv_device_error)
+        HIP_TRY(hipMemsetAsync(h->sched_flag_dev, 0, ((size_t)h->N + 64) * sizeof(uint32_t), (hipStream_t)stream));
+        *(volatile uint32_t *)h->err_host = 0u;
+    }
     return UAVENV_OK;
 }

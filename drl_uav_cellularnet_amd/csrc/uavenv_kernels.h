@@ -109,9 +109,19 @@ struct KParams {
     OutPtrs out;
     unsigned long long *dbg;   // diagnostic builds only (UAVENV_STAMPS): [waves][8] s_memtime stamps
     OutPacked pk;              // uavenv_step_many_packed (PKO kernels): packed output records instead of `out`
-    const int4 *sched;         // multi-step launches: work descriptors [launch waves][2] {env-wavefront, first step, steps, -} of a
-                               // rotation schedule (uavenv_capi.hip: rotation_plan), or null = wave w runs env-wavefront w, all steps
+    const int4 *sched;         // multi-step launches: work descriptors [launch waves][kSchedPieces] {env-wavefront, first step, steps,
+                               // SCHED_* bits} of a rotation schedule (uavenv_capi.hip: rotation_plan), or null = wave w runs
+                               // env-wavefront w, all steps
+    uint32_t *sched_flag;      // [env-wavefronts] hand-off words of the one-launch schedule: 1 = "the first steps of this env-wavefront
+                               // are done and its state is in memory"; set by the producing wavefront, cleared by the consuming one
+    uint32_t *sched_err;       // host-mapped sticky error word of the handle: a hand-off that is not signalled within the spin budget
+                               // stores UAVENV_DEV_ERR_HANDOFF here and the wavefront exits (the host then fails every later call)
+    uint32_t sched_spin_us;    // spin budget of one hand-off wait, in microseconds of s_memrealtime (100 MHz)
 };
+constexpr int kSchedPieces = 3;          // a slot of a one-launch schedule: [first steps of a split job] [whole job] [last steps of another]
+enum : int { SCHED_WAIT = 1,             // piece starts at step t0 > 0: wait for the flag of its env-wavefront, acquire, then load the state
+             SCHED_PUBLISH = 2 };        // piece ends before the call's last step: drain the state stores, release, set the flag
+constexpr uint32_t kDevErrHandoff = 0x48414e44u;   // "HAND": sched_err value of a hand-off that timed out
 
 struct InitParams {
     int U, Gr, B, W64, G, per; int agg_init, deagg_len;
@@ -989,6 +999,42 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
 #endif
 }
 
+// ---- hand-off between the two wavefronts that share a split job of a one-launch schedule -----------------------------------------
+// Producer: its state stores are plain stores; they leave this wavefront (s_waitcnt vmcnt(0)), an agent-scope release writes the
+// XCD's L2 back, and only then the flag goes out (MI355X_MICROARCH.md, "Valid forms": the explicit wait between the release and the
+// flag store is the guide's fix for a compiler pass that drops it).  Consumer: ONE lane polls with relaxed agent-scope loads (they
+// bypass the CU's L1), then an agent-scope acquire invalidates what this CU may hold of the state, then the body's plain loads.
+// The flag is cleared by its consumer, so a captured launch replays correctly and no per-call epoch is needed.
+__device__ __forceinline__ void sched_hand_off_publish(const KParams &p, int ew) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.sched_flag + ew, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false = the flag did not arrive within the budget: the error word is set and the caller must leave the kernel.
+__device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
+    uint32_t *f = p.sched_flag + ew;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long budget = (unsigned long long)p.sched_spin_us * 100ull;           // s_memrealtime ticks at 100 MHz
+    int seen = 0;
+    for (;;) {
+        uint32_t v = 0u;
+        if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = __builtin_amdgcn_readfirstlane((int)v);
+        if (seen != 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_start > budget) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (seen == 0) {
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.sched_err, kDevErrHandoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+    return true;
+}
+
 // PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
@@ -1006,25 +1052,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1);
     } else {
         // Multi-step launch.  Plain: wavefront w hosts env-wavefront w for all p.n_ticks steps.  Rotation schedule (p.sched,
-        // uavenv_capi.hip: rotation_plan): this wavefront is a SLOT that works through up to two segments, each a run of consecutive
-        // steps of one env-wavefront: state loaded, nt steps, state stored.  Segments of one env-wavefront never share a launch, so
-        // the stream order of the launches is the only synchronisation the schedule needs.
-        // (Two inlined copies of the body rather than a loop around one: with the loop hipcc allocated 330 VGPRs for the pinned
-        // kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
+        // uavenv_capi.hip: rotation_plan): this wavefront is a SLOT that works through up to three pieces, each a run of consecutive
+        // steps of one env-wavefront: state loaded, nt steps, state stored.
+        // (Inlined copies of the body rather than a rolled loop around one: with the rolled loop hipcc allocated 330 VGPRs for the
+        // pinned kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
         const int4 *sched = p.sched;
-        int ew = (int)gw, t0 = 0, nt = p.n_ticks;
-        if (sched != nullptr) {
-            const int4 d = sched[gw * 2];                                     // uniform address
-            ew = __builtin_amdgcn_readfirstlane(d.x); t0 = __builtin_amdgcn_readfirstlane(d.y); nt = __builtin_amdgcn_readfirstlane(d.z);
+        if (sched == nullptr) {
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks);
+            return;
         }
-        if (nt > 0) env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
-        if (sched != nullptr) {
-            const int4 d = sched[gw * 2 + 1];
-            ew = __builtin_amdgcn_readfirstlane(d.x); t0 = __builtin_amdgcn_readfirstlane(d.y); nt = __builtin_amdgcn_readfirstlane(d.z);
-            if (nt > 0) {
-                __builtin_amdgcn_wave_barrier();                               // (the first segment's reads of the LDS row are done)
-                env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
-            }
+        // One-launch schedule: this wavefront is a SLOT with up to kSchedPieces pieces.  A piece that starts inside a job (SCHED_WAIT)
+        // waits until the wavefront that ran the job's first steps has published them; a piece that ends inside a job
+        // (SCHED_PUBLISH) publishes.  Publishing pieces come FIRST in their slot and wait for nothing, so every wait ends once its
+        // producer has been scheduled; the wait is bounded all the same (sched_hand_off_wait): a bug becomes an error code, not a hang.
+#pragma unroll
+        for (int q = 0; q < kSchedPieces; ++q) {
+            const int4 d = sched[gw * kSchedPieces + q];                      // uniform address
+            const int ew = __builtin_amdgcn_readfirstlane(d.x), t0 = __builtin_amdgcn_readfirstlane(d.y);
+            const int nt = __builtin_amdgcn_readfirstlane(d.z), bits = __builtin_amdgcn_readfirstlane(d.w);
+            if (nt <= 0) continue;
+            if (q > 0) __builtin_amdgcn_wave_barrier();                       // (the previous piece's reads of the LDS row are done)
+            if (bits & SCHED_WAIT) { if (!sched_hand_off_wait(p, ew)) return; }
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
+            if (bits & SCHED_PUBLISH) sched_hand_off_publish(p, ew);
         }
     }
 }

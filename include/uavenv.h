@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 4   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
+#define UAVENV_ABI_VERSION 5   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
                                 * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
-                                *      uavenv_step_many_prepare */
+                                *      uavenv_step_many_prepare;
+                                * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs) */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -34,7 +35,8 @@ enum {
     UAVENV_E_INVALID = -1,   /* bad argument / config            */
     UAVENV_E_HIP = -2,       /* a HIP runtime call failed        */
     UAVENV_E_NODEVICE = -3,  /* no usable gfx950 device          */
-    UAVENV_E_NOMEM = -4
+    UAVENV_E_NOMEM = -4,
+    UAVENV_E_DEVICE = -5     /* an earlier launch on this handle reported a failure from the device (uavenv_device_error) */
 };
 
 /* Constants of the reference, as data.  uavenv_default_config() fills the values every reference
@@ -207,10 +209,21 @@ void uavenv_debug_variant_reset(void);
 int uavenv_step_many_prepare(uavenv_t *h, int n_steps);
 
 /* Test hook: how uavenv_step_many / uavenv_step_many_packed would run n_steps on this handle: *n_launches = 0 for the plain single
- * launch, else the number of launches of the rotation schedule and *slots wavefronts per launch.  Environment,
- * read once in uavenv_create: UAVENV_ROTATE=0 never rotate, =1 rotate whenever a valid schedule exists; UAVENV_ROTATE_SLOTS=k
- * plan as if the device had k SIMDs (lets small batches exercise the schedule). */
+ * launch, else the number of launches of the rotation schedule (1 = the one-launch schedule with hand-offs
+ * between wavefronts) and *slots wavefronts per launch.  Environment, read once in uavenv_create: UAVENV_ROTATE=0 never rotate,
+ * =1 the one-launch schedule whenever a valid one exists, =2 the several-launch schedule of ABI 4 whenever a valid one exists
+ * (A/B runs); UAVENV_ROTATE_SLOTS=k plan as if the device had k SIMDs (lets small batches exercise the schedule);
+ * UAVENV_HANDOFF_SPIN_US=n spin budget of one hand-off wait (default 2 000 000); UAVENV_DEBUG_DROP_PUBLISH=1 builds schedules
+ * whose hand-offs are never signalled (the time-out path's test). */
 int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots);
+
+/* Sticky device-side error of a handle: *code = 0, or the word a kernel left when it gave up (0x48414e44 "HAND": a wavefront of a
+ * one-launch schedule waited longer than the spin budget for the wavefront that runs the first steps of the same envs -- never seen
+ * outside the test hook, but a bounded wait is what turns a scheduling bug into an error code instead of a hung GPU).  The word lives
+ * in host-mapped memory: reading it costs no HIP call, and it is meaningful once the stream of the failing launch has been
+ * synchronised.  While it is non-zero every stepping / reset / state-reading entry point of the handle returns UAVENV_E_DEVICE;
+ * uavenv_set_state() installs a whole state again and clears it. */
+int uavenv_device_error(uavenv_t *h, uint32_t *code);
 
 /* Philox4x32-10 of one counter/key on the HOST (known-answer tests of the generator the kernels use). */
 void uavenv_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

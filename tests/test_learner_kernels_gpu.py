@@ -574,3 +574,64 @@ def test_graph_captured_rollout_equals_the_eager_rollout():
         r2.update(*b2)
         assert torch.equal(r1.flat.w, r2.flat.w)                   # deterministic kernels: the twins stay bit-identical
     assert r1.running_r is not None and r1.running_r == r2.running_r
+
+
+def test_fused_update_is_bit_identical_with_and_without_forward_reuse():
+    """update_fused computes the critic's layer 2 with ONE arithmetic (W2^T through the k-contiguous kernels) whether it reuses the
+    rollout's forward pass or recomputes it (first update after load_state_dict, external buffers): same parameters bit for bit
+    (the two branches used kernels with different k orders)."""
+    torch = _torch()
+    r1, r2 = _twin_runners(torch, 700, 5, first=dict(collect_launch="eager"), second=dict(collect_launch="eager"))
+    for it in range(2):
+        b1, b2 = r1.collect(), r2.collect()
+        r2._fwd_valid = False                          # r2 recomputes the forward pass with the same weights
+        s1, s2 = r1.update(*b1), r2.update(*b2)
+        assert s1["forward_reused"] and not s2["forward_reused"]
+        assert torch.equal(r1.flat.g, r2.flat.g) and torch.equal(r1.flat.w, r2.flat.w) and torch.equal(r1.flat.ms, r2.flat.ms)
+
+
+def test_gemm_wrappers_validate_their_operands():
+    """gemm_rows / gemm_tn / actor_head refuse short or mistyped side outputs instead of letting a kernel overrun them."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    a = torch.randn(256, 200, device="cuda")
+    w = torch.randn(200, 200, device="cuda")
+    out = torch.empty(256, 200, device="cuda")
+    ws = A.gemm_rows_workspace(256, "cuda")
+    with pytest.raises(A.UavAgentError):               # column sums shorter than N
+        A.gemm_rows(a, w, out, w_transposed=True, colsum_out=torch.empty(100, device="cuda"), workspace=ws)
+    with pytest.raises(A.UavAgentError):               # wrong dtype
+        A.gemm_rows(a, w, out, w_transposed=True, colsum_out=torch.empty(200, device="cuda", dtype=torch.float64), workspace=ws)
+    with pytest.raises(A.UavAgentError):               # bias of the wrong length
+        A.gemm_rows(a, w, out, w_transposed=True, bias=torch.empty(199, device="cuda"))
+    with pytest.raises(A.UavAgentError):               # an operand on the host
+        A.gemm_rows(a, w.cpu(), out, w_transposed=True)
+    with pytest.raises(A.UavAgentError):               # mask of another shape
+        A.gemm_rows(a, w, out, w_transposed=True, relu6_mask_h=torch.empty(255, 200, device="cuda"))
+    cs = torch.empty(200, device="cuda")
+    A.gemm_rows(a, w, out, w_transposed=True, colsum_out=cs, workspace=ws)       # the valid call still runs
+    torch.testing.assert_close(cs, out.sum(dim=0), rtol=1e-4, atol=1e-3)
+    with pytest.raises(A.UavAgentError):
+        A.gemm_tn(a, out, torch.empty(200, 200, device="cuda"), None)
+
+
+def test_gemm_tuning_is_frozen_after_the_first_rollout_and_update():
+    """A2CRunner(tune_gemms=True): TunableOp may tune while the first rollout + update run eagerly, never afterwards."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import BatchedMobiEnv, agent
+
+    env = BatchedMobiEnv(256, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+    r = agent.A2CRunner(env, rollout=3, tune_gemms=True)
+    if not r.gemm_tuning:
+        pytest.skip("torch.cuda.tunable unavailable")
+    import torch.cuda.tunable as tun
+
+    try:
+        r.train_rollout()
+        assert not agent.gemm_tuning_is_active()
+        assert tun.is_enabled()                        # the picks stay in use
+        r.train_rollout()
+        assert not agent.gemm_tuning_is_active()
+    finally:
+        tun.enable(False)                              # (the other tests of this process run on the library defaults)

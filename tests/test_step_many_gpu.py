@@ -96,34 +96,39 @@ def test_step_many_packed_unpacks_to_exactly_what_step_many_returns(shape, pin, 
         assert torch.equal(got2[k], want[k]), k
 
 
-# (n_envs, n_bs, n_ue, T, slots): W = ceil(n_envs / envs per wavefront) env-wavefronts planned onto `slots` pretend-SIMDs
+# (n_envs, n_bs, n_ue, T, slots): W = ceil(n_envs / envs per wavefront) env-wavefronts planned onto k x `slots` slots, k = W // slots
 ROT_SHAPES = [(100, 4, 20, 7, 24), (100, 4, 20, 50, 26), (301, 4, 20, 33, 80), (50, 4, 40, 9, 37), (33, 3, 20, 6, 8), (20, 8, 20, 5, 5),
-              (10, 16, 60, 6, 7), (64, 4, 20, 100, 16)]
+              (10, 16, 60, 6, 7), (64, 4, 20, 100, 16),
+              (100, 4, 20, 21, 13), (301, 4, 20, 40, 29), (64, 4, 20, 12, 5)]      # k = 2, 3, 4 resident wavefronts per pretend-SIMD
 
 
+@pytest.mark.parametrize("form", ["1", "2"], ids=["one_launch", "several_launches"])
 @pytest.mark.parametrize("packed_out", [False, True], ids=["nine_arrays", "packed_records"])
 @pytest.mark.parametrize("shape", ROT_SHAPES, ids=lambda s: "%denv_%dx%d_T%d_S%d" % s)
-def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, monkeypatch):
-    """A multi-step call on S < W < 2 S wavefronts is run as several launches of S wavefronts, each working through segments
-    (env-wavefront, first step, steps) of a wrap-around schedule (csrc/uavenv_capi.hip: rotation_plan).  Same steps, same order per
-    env: every output of every step and the final state must equal the single plain launch.  UAVENV_ROTATE_SLOTS makes small batches
-    plan as if the device had that few SIMDs; at BASELINE's 4096 envs the schedule is chosen automatically
-    (tests/test_full_size_parity_gpu.py compares that run with the oracle)."""
+def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, form, monkeypatch):
+    """A multi-step call on S < W < 2 S wavefronts runs as S persistent wavefronts, each working through up to three pieces
+    (env-wavefront, first step, steps) of a wrap-around schedule (csrc/uavenv_capi.hip: rotation_plan); the two wavefronts that share
+    a split job hand its state over through memory + a flag (form 1, one launch), or the schedule is cut into several launches and stream
+    order does it (form 2, round 3).  Same steps, same order per env: every output of every step and the final state must equal the
+    single plain launch.  UAVENV_ROTATE_SLOTS makes small batches plan as if the device had that few SIMDs; at BASELINE's 4096 envs
+    the schedule is chosen automatically (tests/test_full_size_parity_gpu.py compares that run with the oracle)."""
     torch = _torch()
     import ctypes as C
 
     n, n_bs, n_ue, T, slots = shape
-    monkeypatch.setenv("UAVENV_ROTATE", "1")
+    monkeypatch.setenv("UAVENV_ROTATE", form)
     monkeypatch.setenv("UAVENV_ROTATE_SLOTS", str(slots))
     env = _env(n, n_bs, n_ue)
     monkeypatch.setenv("UAVENV_ROTATE", "0")
     ref = env.clone()
+    W = -(-n // max(1, 64 // n_ue)) if n_ue <= 64 else n
     nl, sl = C.c_int(-1), C.c_longlong(-1)
     assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
-    assert nl.value >= 2 and sl.value == slots, (nl.value, sl.value)            # the rotated handle really rotates ...
+    assert sl.value == (W // slots) * slots, (nl.value, sl.value)
+    assert (nl.value == 1) if form == "1" else (nl.value >= 2), nl.value       # the rotated handle really rotates ...
     assert ref._lib.uavenv_debug_rotation_info(ref._h, T, C.byref(nl), C.byref(sl)) == 0 and nl.value == 0    # ... the reference does not
     act = _actions(torch, env, T, 8)
-    for rep in range(2):                                                        # second call: cached schedule, continues from the stored state
+    for rep in range(3):                                                        # later calls: cached schedule, flags cleared by their consumers
         if packed_out:
             got = env.unpack_outputs(env.step_many_packed(act))
             want = ref.unpack_outputs(ref.step_many_packed(act))
@@ -132,22 +137,111 @@ def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_ou
         for k in want:
             assert torch.equal(got[k], want[k]), "%s differs (call %d)" % (k, rep)
         assert np.array_equal(env.get_state(), ref.get_state())
+        assert env.device_error() == 0
 
 
-def test_rotation_is_automatic_at_the_baseline_batch_and_off_elsewhere():
+def test_one_launch_rotation_replays_from_a_captured_graph(monkeypatch):
+    """The hand-off flags are cleared by the wavefront that consumed them, so a captured multi-step launch replays correctly (a
+    per-call epoch in the kernel arguments would not); a schedule that does not exist yet is not built inside a capture (the plain
+    launch is captured instead)."""
+    torch = _torch()
+    import ctypes as C
+
+    monkeypatch.setenv("UAVENV_ROTATE", "1")
+    monkeypatch.setenv("UAVENV_ROTATE_SLOTS", "24")
+    env = _env(100, 4, 20)
+    cold = env.clone()                                            # never prepared: its capture must fall back to the plain launch
+    monkeypatch.setenv("UAVENV_ROTATE", "0")
+    ref = env.clone()
+    T = 9
+    act = _actions(torch, env, T, 5)
+    assert env._lib.uavenv_step_many_prepare(env._h, T) == 0
+    outs = {}
+    graphs = {}
+    for name, e in (("warm", env), ("cold", cold)):
+        outs[name] = e.step_many(act) if name == "warm" else {k: torch.empty((T,) + tuple(v.shape), dtype=v.dtype, device=e.device) for k, v in e.out.items()}
+        if name == "warm":
+            want = ref.step_many(act)
+            for k in want:
+                assert torch.equal(outs[name][k], want[k])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                e.step_many(act, out=outs[name], refresh_out=False)
+        graphs[name] = g
+    nl = C.c_int(-1)
+    assert cold._lib.uavenv_debug_rotation_info(cold._h, T, C.byref(nl), None) == 0 and nl.value == 1     # (built now, outside the capture)
+    cold_ref = ref.clone()
+    cold_ref.set_state(cold.get_state())
+    for rep in range(3):
+        graphs["warm"].replay()
+        want = ref.step_many(act)
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(outs["warm"][k], want[k]), "%s differs (replay %d)" % (k, rep)
+        assert np.array_equal(env.get_state(), ref.get_state())
+        graphs["cold"].replay()
+        want = cold_ref.step_many(act)
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(outs["cold"][k], want[k]), "%s differs (cold replay %d)" % (k, rep)
+    assert env.device_error() == 0 and cold.device_error() == 0
+
+
+def test_a_hand_off_that_is_never_signalled_becomes_an_error_code_not_a_hang(monkeypatch):
+    """UAVENV_DEBUG_DROP_PUBLISH builds a schedule whose publishing pieces never set their flag.  The waiting wavefronts give up after
+    the spin budget (2 ms here), leave UAVENV_DEV_ERR_HANDOFF in the handle's host-mapped error word and exit; the launch ends, every
+    later call on the handle fails with UAVENV_E_DEVICE, and set_state() makes it usable again."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _capi
+
+    monkeypatch.setenv("UAVENV_ROTATE", "1")
+    monkeypatch.setenv("UAVENV_ROTATE_SLOTS", "24")
+    good = _env(100, 4, 20)
+    monkeypatch.setenv("UAVENV_DEBUG_DROP_PUBLISH", "1")
+    monkeypatch.setenv("UAVENV_HANDOFF_SPIN_US", "2000")
+    bad = good.clone()
+    monkeypatch.delenv("UAVENV_DEBUG_DROP_PUBLISH")
+    state0 = good.get_state()
+    act = _actions(torch, good, 7, 2)
+    want = good.step_many(act)
+    assert good.device_error() == 0
+    bad.step_many(act, refresh_out=False)                        # the launch itself is asynchronous: it returns 0
+    torch.cuda.synchronize()                                      # ... and ENDS (bounded wait), with the error word set
+    assert bad.device_error() == 0x48414E44
+    with pytest.raises(_capi.UavEnvError, match="hand-off"):
+        bad.step(act[0])
+    with pytest.raises(_capi.UavEnvError):
+        bad.get_state()
+    bad.set_state(state0)                                         # a whole state again: the error is cleared ...
+    assert bad.device_error() == 0
+    monkeypatch.setenv("UAVENV_ROTATE", "0")
+    ok = bad.clone()                                              # ... and a handle without the broken schedule continues from it
+    got = ok.step_many(act)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_rotation_is_automatic_where_it_pays_and_off_elsewhere():
+    """Automatic use (no UAVENV_ROTATE): k = W // SIMDs resident wavefronts per SIMD with 1 <= k <= 2 (the pinned kernel's occupancy),
+    1 < W / (k SIMDs) <= 1.45, at least 16 steps per call; always the one-launch form."""
     torch = _torch()
     import ctypes as C
 
     n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     nl, sl = C.c_int(-1), C.c_longlong(-1)
-    for n, T, expect in ((4096, 100, True), (4096, 48, True), (4096, 20, False), (3072, 100, False), (6144, 100, False), (8192, 100, False), (4096, 4, False)):
+    for n, T in ((4096, 100), (4096, 48), (4096, 20), (4096, 16), (4096, 8), (3072, 100), (3500, 100), (6144, 100), (8192, 100), (8192, 20), (9100, 100),
+                 (12288, 100), (1536, 100)):
         env = _env(n, 4, 20)
         assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
         waves = (n + 2) // 3
-        want = expect and (1.2 * n_simd <= waves <= 1.45 * n_simd)              # (a device with another CU count shifts the band)
-        assert (nl.value > 0) == want, (n, T, nl.value, n_simd)
+        k = waves // n_simd
+        want = 1 <= k <= 2 and waves > k * n_simd and 100 * waves <= 145 * k * n_simd and T >= 16
+        assert (nl.value == 1) == want and nl.value in (0, 1), (n, T, nl.value, n_simd)
         if nl.value:
-            assert sl.value == n_simd and 2 <= nl.value <= 6
+            assert sl.value == k * n_simd
 
 
 def test_step_many_packed_rejects_bad_arguments():
