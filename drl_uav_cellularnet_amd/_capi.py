@@ -57,7 +57,7 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_many", "uavenv_step_many_packed", "uavenv_unpack_outputs", "uavenv_step_seq", "uavenv_step_trace",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_step_many", "uavenv_step_many_packed", "uavenv_unpack_outputs", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area", "uavenv_sinr_area_at",
            "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset", "uavenv_debug_rotation_info", "uavenv_step_many_prepare", "uavenv_device_error",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
@@ -97,6 +97,7 @@ def load():
     lib.uavenv_reset.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_reset_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_step_range.argtypes = [_P, _P, C.c_int64, C.c_int64, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_seq.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many_packed.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOutPacked), _P]

@@ -330,7 +330,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=True):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -370,6 +370,21 @@ class A2CRunner:
         # instead of a separate obs_indices launch after every env step
         self.fused_obs = bool(fused_obs) and env.nBS + env.nUE <= 64
         self._side = None
+        # pipeline_halves (GPU, fused_head + fused_obs): the workers of a2c_single_thread.py:113-118 are independent of each other for a
+        # whole rollout, so the batch is cut in two halves that ping-pong on two streams inside the rollout (and inside its captured
+        # graph): while the actor's head of one half runs (MFMA / LDS-DMA bound, half the CUs), the other half steps its envs and
+        # gathers its first layer (fabric bound, no MFMA).  The two heads never overlap each other (events), which is what keeps the
+        # halves out of lockstep.  Same kernels on the same rows with the same uniforms: bit-identical to the unsplit rollout.
+        # True = when each half still fills the chip (>= 4096 envs), "force" = whenever the batch can be cut (tests).
+        self._halves = None
+        self._pipe_stream = None
+        if pipeline_halves and self.dev.type == "cuda" and self.fused_head and self.fused_obs:
+            import math
+
+            unit = math.lcm(int(env.envs_per_wavefront), 32)          # env wavefronts and the head's 32-row tiles both stay whole
+            cut = (env.n_envs // 2 + unit - 1) // unit * unit
+            if 0 < cut < env.n_envs and (pipeline_halves == "force" or env.n_envs >= 4096):
+                self._halves = ((0, cut), (cut, env.n_envs))
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
         # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
@@ -431,6 +446,8 @@ class A2CRunner:
     def _rollout_steps(self):
         """The T-step loop: choose_action (main.py:165-169) -> env.step -> next observation.  No host synchronisation, no
         allocation visible to the caller: capturable."""
+        if self._halves is not None:
+            return self._rollout_steps_pipelined()
         env, T, net = self.env, self.T, self.net
         self.idx_buf[0].copy_(self.idx_buf[T])
         cuda = self.dev.type == "cuda"
@@ -467,6 +484,46 @@ class A2CRunner:
             env.step(self.act_buf[t], reward_out=self.rew_buf[t])
             if not fused_obs or t == T - 1:
                 self._indices_into(self.idx_buf[t + 1])
+
+    def _rollout_steps_pipelined(self):
+        """The T-step loop with the batch cut in two halves on two streams (see pipeline_halves in __init__).  Per half and step:
+        first layer from the observation the half's previous step left (gather), actor head, env step of the half's envs
+        (uavenv_step_range).  Cross-stream order: head(B, t) after head(A, t), head(A, t + 1) after head(B, t).  Capturable: the
+        second stream forks from and joins the calling stream through events."""
+        from . import _agent_capi as A
+
+        env, T, net, fw, wt = self.env, self.T, self.net, self._fwd, self._wt
+        self.idx_buf[0].copy_(self.idx_buf[T])
+        main = torch.cuda.current_stream(self.dev)
+        if self._pipe_stream is None:
+            self._pipe_stream = torch.cuda.Stream(device=self.dev)
+        side = self._pipe_stream
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        obs = env.observation()
+        head_done = [None, None]
+        for t in range(T):
+            for h, ((lo, hi), st) in enumerate(zip(self._halves, (main, side))):
+                with torch.cuda.stream(st):
+                    if t == 0:
+                        A.sparse_rows_sum(self.idx_buf[0][lo:hi], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][0][lo:hi],
+                                          out_c=fw["h1c"][0][lo:hi])
+                    else:
+                        A.first_layer_from_obs({k: v[lo:hi] for k, v in obs.items()}, self.G, net.a_w1, net.a_b1, net.c_w1, net.c_b1,
+                                               fw["h1a"][t][lo:hi], fw["h1c"][t][lo:hi], idx_out=self.idx_buf[t][lo:hi])
+                    if head_done[1 - h] is not None:
+                        st.wait_event(head_done[1 - h])              # the two heads alternate; everything else overlaps them
+                    A.actor_head(fw["h1a"][t][lo:hi], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf[t][lo:hi], net.n_action,
+                                 fw["h2a"][t][lo:hi], self._logits_pad[t][lo:hi], self.act_buf[t][lo:hi])
+                    head_done[h] = torch.cuda.Event()
+                    head_done[h].record(st)
+                    env.step_range(self.act_buf[t], lo, hi - lo, reward_out=self.rew_buf[t])
+                    if t == T - 1:
+                        A.obs_indices({k: v[lo:hi] for k, v in obs.items()}, self.G, self.B, out=self.idx_buf[T][lo:hi])
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
 
     @torch.no_grad()
     def collect(self):

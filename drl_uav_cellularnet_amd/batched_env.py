@@ -221,6 +221,28 @@ class BatchedMobiEnv:
         return self.observation(), o["reward"], o["done"], {"mean_sinr": o["mean_sinr"], "n_out": o["n_out"],
                                                              "step_n": o["step_n"], "cur_sinr": o["cur_sinr"]}
 
+    @property
+    def envs_per_wavefront(self):
+        """Env instances one wavefront of the step kernel hosts (ranges of step_range start and end on multiples of it)."""
+        packed = self.nUE <= 64 and self.nUE >= self.nBS and self.nUE >= int(self.cfg.n_groups)
+        return min(64 // self.nUE, 8) if packed else 1
+
+    def step_range(self, actions, first_env, n_envs, reward_out=None):
+        """step() for envs [first_env, first_env + n_envs) only (uavenv_step_range).  ``actions`` / ``reward_out`` are the WHOLE batch's
+        [N] tensors; only the range's entries are read / written, and only the range's slices of ``self.out`` change.  Ranges that do
+        not overlap may be stepped concurrently on different streams.  No return value: read ``self.out`` / observation()."""
+        a = self._actions(actions)
+        out_ref = self._out_ref
+        if reward_out is not None:
+            if reward_out.dtype != torch.float32 or reward_out.numel() != self.n_envs or not reward_out.is_contiguous():
+                raise ValueError("reward_out must be a contiguous float32 [n_envs] tensor")
+            st = _capi.UavEnvOut.from_buffer_copy(self._out_struct)
+            st.reward_dev = reward_out.data_ptr()
+            out_ref = C.byref(st)
+        rc = self._lib.uavenv_step_range(self._h, a.data_ptr(), int(first_env), int(n_envs), None, out_ref, self._stream())
+        if rc:
+            _capi.check(rc)
+
     def capture_steps(self, actions):
         """A hipGraph of len(actions) step() launches (one kernel node per step, step t reading ``actions[t]``): ``g.replay()``
         then costs one graph launch instead of T host calls -- the per-step host cost (ctypes call + hipLaunchKernel, ~8 us

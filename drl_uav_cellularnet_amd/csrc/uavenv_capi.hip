@@ -412,16 +412,22 @@ extern "C" void uavenv_debug_variant_reset(void) {
 
 // MANY_: 0 = one step / reset / tick batch per launch, 1 = uavenv_step_many (nine output arrays), 2 = uavenv_step_many_packed
 template <int MODE, int MANY_ = 0>
-static int launch_env(uavenv_t *h, const KParams &p, hipStream_t s, long long launch_waves = 0) {
+static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long launch_waves = 0, long long first_env = 0, long long n_range = 0) {
     constexpr bool MANY = MANY_ != 0, PKO = MANY_ == 2;
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
-    const long long waves = (p.N + p.epw - 1) / p.epw;
+    // (n_range > 0: envs [first_env, first_env + n_range) only -- uavenv_step_range has checked that the range starts on a wavefront
+    //  boundary and ends on one or at N)
+    KParams p = p_in;
+    const long long n_here = n_range > 0 ? n_range : p.N;
+    const long long waves = (n_here + p.epw - 1) / p.epw;
+    const int wave0 = (int)(first_env / p.epw);
+    p.wave0 = wave0; p.e_end = n_range > 0 ? first_env + n_range : p.N;
     // (a launch of a rotation schedule has `launch_waves` slots instead of one wavefront per env-wavefront; p.sched says who does what)
     const unsigned grid = (unsigned)(((launch_waves > 0 ? launch_waves : waves) + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
     // leading scalar arguments of the packed kernels: delivered in SGPRs at wave launch (kernarg preload), see
     // env_kernel_packed.  The slab base replaces the 19 per-field pointers (state_layout.h).
-#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), p
+#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), wave0, p
     if (MODE == MODE_WARMUP) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
         const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4
@@ -535,6 +541,21 @@ extern "C" int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnv
     fill_call(p, inj, out);
     p.actions = (const long long *)actions_dev; p.n_ticks = 1;
     return launch_env<MODE_STEP>(h, p, (hipStream_t)stream);
+}
+
+extern "C" int uavenv_step_range(uavenv_t *h, const int64_t *actions_dev, int64_t first_env, int64_t n_envs, const UavEnvInject *inj,
+                                 const UavEnvOut *out, void *stream) {
+    if (!h || !actions_dev) return fail(UAVENV_E_INVALID, "step_range: null handle or actions");
+    const long long epw = h->kp.epw;
+    if (first_env < 0 || n_envs < 1 || first_env + n_envs > h->N || first_env % epw != 0 || ((first_env + n_envs) % epw != 0 && first_env + n_envs != h->N))
+        return fail(UAVENV_E_INVALID, "step_range: the range must lie inside the batch, start on a multiple of " + std::to_string(epw) +
+                                      " envs (one wavefront hosts that many) and end on one or at n_envs");
+    DeviceGuard guard(h->device);
+    if (int rc_dev = poisoned(h, "step_range")) return rc_dev;
+    KParams p = h->kp;
+    fill_call(p, inj, out);
+    p.actions = (const long long *)actions_dev; p.n_ticks = 1;
+    return launch_env<MODE_STEP>(h, p, (hipStream_t)stream, 0, first_env, n_envs);
 }
 
 // Output block of step t in the [T][...] arrays of a multi-step call (uavenv_step_many); null members stay null.

@@ -117,6 +117,8 @@ struct KParams {
     uint32_t *sched_err;       // host-mapped sticky error word of the handle: a hand-off that is not signalled within the spin budget
                                // stores UAVENV_DEV_ERR_HANDOFF here and the wavefront exits (the host then fails every later call)
     uint32_t sched_spin_us;    // spin budget of one hand-off wait, in microseconds of s_memrealtime (100 MHz)
+    int wave0;                 // multi-pass kernel: first env of the launch (uavenv_step_range; the packed kernel takes it as a scalar argument)
+    long long e_end;           // multi-pass kernel: one past the last env of the launch (N, or the end of the range)
 };
 constexpr int kSchedPieces = 3;          // a slot of a one-launch schedule: [first steps of a split job] [whole job] [last steps of another]
 enum : int { SCHED_WAIT = 1,             // piece starts at step t0 > 0: wait for the flag of its env-wavefront, acquire, then load the state
@@ -1039,7 +1041,7 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
-                                                                              int Gr, int B_rt, int lane_magic, const KParams p) {
+                                                                              int Gr, int B_rt, int lane_magic, int wave0, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
     static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
@@ -1047,7 +1049,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
     __shared__ int s_bs[kWavesPerBlock][kMaxEpw][2 * kMaxBs];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave;     // this wavefront's index in the launch (uniform)
+    // this wavefront's env-wavefront (uniform).  wave0 > 0: a launch over a RANGE of the batch (uavenv_step_range: envs wave0 * EPW ...)
+    const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave + wave0;
     if (!MANY) {
         env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1);
     } else {
@@ -1167,8 +1170,8 @@ void env_kernel_multipass(const KParams p) {
     kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long e = (long long)blockIdx.x * kWavesPerBlock + wave;  // wave-uniform
-    if (e >= p.N) return;
+    const long long e = (long long)blockIdx.x * kWavesPerBlock + wave + p.wave0;  // wave-uniform (wave0 > 0: uavenv_step_range)
+    if (e >= p.e_end) return;
     if (is_reset(MODE)) { if (p.mask != nullptr && p.mask[e] == 0) return; }
     // Constants stay unpinned (SGPRs / literals).  Measured on one box at 8192 envs of 16 x 200 (profiles/r02c_*): pinning them
     // in VGPRs as the packed kernel's PIN variant does: -12 % instructions but 187 VGPRs = 2 wavefronts per SIMD, 151.5 vs

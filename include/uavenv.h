@@ -26,7 +26,7 @@ extern "C" {
 #define UAVENV_ABI_VERSION 5   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
                                 * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
                                 *      uavenv_step_many_prepare;
-                                * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs) */
+                                * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs), uavenv_step_range */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -128,6 +128,14 @@ int uavenv_reset(uavenv_t *h, const uint8_t *mask_dev, const UavEnvInject *inj, 
 /* MobiEnvironment.step (mobile_env.py:150-194): one fused kernel launch for all N envs. */
 int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj, const UavEnvOut *out,
                 void *stream);
+
+/* The same step for the envs [first_env, first_env + n_envs) of the batch only (all pointers are still those of the WHOLE batch: the
+ * kernel indexes them by env).  For callers that pipeline parts of a batch on several streams -- the A2C rollout steps one half
+ * while the policy network works on the other (a2c_single_thread.py:113-118: the workers are independent of each other).  The
+ * range must start on a multiple of the envs one wavefront hosts (floor(64 / n_ue) when n_ue <= 64 and n_ue >= n_bs, n_groups; else 1)
+ * and end on one or at n_envs: UAVENV_E_INVALID otherwise.  Ranges that do not overlap may run concurrently. */
+int uavenv_step_range(uavenv_t *h, const int64_t *actions_dev, int64_t first_env, int64_t n_envs, const UavEnvInject *inj,
+                      const UavEnvOut *out, void *stream);
 /* n_steps consecutive MobiEnvironment.step calls (mobile_env.py:150-194) in ONE launch, for callers whose actions do not depend on
  * the observations in between (a random policy, main.py's warm-up exploration; an action tape): actions_dev is [n_steps, N]
  * (step t uses row t) and every non-NULL member of `out` points to n_steps consecutive blocks of the single-step shape, e.g.

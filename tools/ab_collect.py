@@ -6,7 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from drl_uav_cellularnet_amd import BatchedMobiEnv
 from drl_uav_cellularnet_amd.agent import A2CRunner
-variants = {"default": {}, "separate_obs_indices": {"fused_obs": False}, "three_launches": {"fused_head": False}, "torch_gemms": {"hip_gemms": False}}
+variants = {"default (pipelined halves)": {}, "unsplit (round 3)": {"pipeline_halves": False}, "separate_obs_indices": {"fused_obs": False},
+            "three_launches": {"fused_head": False}}
+if len(sys.argv) > 1:
+    variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
 runners = {}
 for k, kw in variants.items():
     env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
