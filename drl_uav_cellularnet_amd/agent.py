@@ -330,7 +330,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=True):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=False):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -378,6 +378,9 @@ class A2CRunner:
         # True = when each half still fills the chip (>= 4096 envs), "force" = whenever the batch can be cut (tests).
         self._halves = None
         self._pipe_stream = None
+        import os as _os
+
+        self.pipeline_mode = _os.environ.get("UAVAGENT_PIPE_MODE", "alternate")    # "alternate" | "stagger" (A/B runs: tools/ab_collect.py)
         if pipeline_halves and self.dev.type == "cuda" and self.fused_head and self.fused_obs:
             import math
 
@@ -503,16 +506,22 @@ class A2CRunner:
         side.wait_event(fork)
         obs = env.observation()
         head_done = [None, None]
+        alternate = self.pipeline_mode == "alternate"
         for t in range(T):
             for h, ((lo, hi), st) in enumerate(zip(self._halves, (main, side))):
                 with torch.cuda.stream(st):
+                    if t == 0 and h == 1 and not alternate:          # "stagger": the second half starts one gather late, then runs free
+                        st.wait_event(first_gather)
                     if t == 0:
                         A.sparse_rows_sum(self.idx_buf[0][lo:hi], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][0][lo:hi],
                                           out_c=fw["h1c"][0][lo:hi])
                     else:
                         A.first_layer_from_obs({k: v[lo:hi] for k, v in obs.items()}, self.G, net.a_w1, net.a_b1, net.c_w1, net.c_b1,
                                                fw["h1a"][t][lo:hi], fw["h1c"][t][lo:hi], idx_out=self.idx_buf[t][lo:hi])
-                    if head_done[1 - h] is not None:
+                    if t == 0 and h == 0 and not alternate:
+                        first_gather = torch.cuda.Event()
+                        first_gather.record(st)
+                    if alternate and head_done[1 - h] is not None:
                         st.wait_event(head_done[1 - h])              # the two heads alternate; everything else overlaps them
                     A.actor_head(fw["h1a"][t][lo:hi], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf[t][lo:hi], net.n_action,
                                  fw["h2a"][t][lo:hi], self._logits_pad[t][lo:hi], self.act_buf[t][lo:hi])

@@ -427,7 +427,7 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     const dim3 blk(64 * kWavesPerBlock);
     // leading scalar arguments of the packed kernels: delivered in SGPRs at wave launch (kernarg preload), see
     // env_kernel_packed.  The slab base replaces the 19 per-field pointers (state_layout.h).
-#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), wave0, p
+#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), wave0, (n_range > 0 ? wave0 + (int)waves : 0), p
     if (MODE == MODE_WARMUP) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
         const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4

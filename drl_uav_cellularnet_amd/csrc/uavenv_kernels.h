@@ -1041,7 +1041,7 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
-                                                                              int Gr, int B_rt, int lane_magic, int wave0, const KParams p) {
+                                                                              int Gr, int B_rt, int lane_magic, int wave0, int wave_end, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
     static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // this wavefront's env-wavefront (uniform).  wave0 > 0: a launch over a RANGE of the batch (uavenv_step_range: envs wave0 * EPW ...)
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave + wave0;
+    if (wave0 != 0 || wave_end != 0) { if (gw >= wave_end) return; }   // a range launch: the last workgroup's surplus wavefronts belong to the next range
     if (!MANY) {
         env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1);
     } else {

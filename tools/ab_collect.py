@@ -10,8 +10,11 @@ variants = {"default (pipelined halves)": {}, "unsplit (round 3)": {"pipeline_ha
             "three_launches": {"fused_head": False}}
 if len(sys.argv) > 1:
     variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
+variants["pipelined, free-running with a one-gather stagger"] = {"_mode": "stagger"}
 runners = {}
 for k, kw in variants.items():
+    kw = dict(kw)
+    os.environ["UAVAGENT_PIPE_MODE"] = kw.pop("_mode", "alternate")
     env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
     runners[k] = A2CRunner(env, rollout=50, **kw)
     runners[k].collect(); runners[k].collect()
