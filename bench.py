@@ -49,6 +49,9 @@ PREWARM_STEPS = 400           # untimed steps on a scratch env right before the 
 CPU_THREAD_CAP = 16           # cpu_baseline threads: the CPU share of a one-GPU job on this pool (stated in the line)
 
 
+SCHEDULE_NAMES = {0: "plain", 1: "one_launch_rotation", 2: "several_launch_rotation"}   # uavenv_debug_rotation_info: launches per call
+
+
 def algorithmic_bytes_per_env_step(U, B, Gr):
     """compact state read+write + outputs, on-device RNG."""
     return 48 * U + 2 * ((U + 7) // 8) + 96 * Gr + 16 * B + 45
@@ -63,21 +66,28 @@ def transcendental_evals_per_env_step(U, B):
     return U * (4 + 3 * hb + 2 * B)
 
 
-def committed_counters(envs, n_bs, n_ue, kernel):
-    """Per-launch PMC figures of a step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
+def committed_counters(envs, n_bs, n_ue, kernel, steps_per_call, schedule):
+    """Per-CALL PMC figures of a step kernel from the COMMITTED rocprofv3 passes (profiles/traffic_current.json): bench.py
     cannot run the profiler on itself, so these are constants of the profiled build, labelled as such in the line.  `kernel` is the
-    instantiation the timed region launched, as the library's launch census names it.  None when no committed pass describes this
-    (kernel, batch size, shape)."""
+    instantiation the timed region launched, as the library's launch census names it.  An entry describes ONE dispatch form: it is used
+    only when batch size, shape, kernel, steps per call AND schedule (plain launch / one-launch rotation / several launches) are those of
+    this run -- nothing is scaled from another form (VERDICT r3 weak #5); otherwise -> (None, why)."""
     path = os.path.join(ROOT, "profiles", "traffic_current.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "profiles/traffic_current.json missing or unreadable"
+    near = []
     for e in t.get("entries", []):
         if (e.get("envs"), e.get("n_bs"), e.get("n_ue"), e.get("kernel")) == (envs, n_bs, n_ue, kernel):
-            return e
-    return None
+            if (e.get("steps_per_launch"), e.get("schedule", "plain")) == (steps_per_call, schedule):
+                return e, None
+            near.append("%s steps per call, %s" % (e.get("steps_per_launch"), e.get("schedule", "plain")))
+    if near:
+        return None, ("no committed PMC pass of this dispatch form (%d steps per call, %s); committed for this kernel and batch: %s"
+                      % (steps_per_call, schedule, "; ".join(near)))
+    return None, "no committed PMC pass of this kernel at this batch size and shape"
 
 
 def launched_kernels(before, after):
@@ -219,6 +229,8 @@ def parse_args(argv):
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
     ap.add_argument("--mode", choices=("env", "a2c"), default="env")
     ap.add_argument("--launch", choices=("many", "manypk", "seq", "graph", "eager"), default="many")
+    ap.add_argument("--chunk", type=int, default=CHUNK, help="steps per uavenv_step_many launch / per captured graph (default 100; profiling "
+                    "runs use 20 to repeat the launch shape of the driver's --steps 20 call)")
     ap.add_argument("--grid", type=int, default=GRID, help="grid cells per side (100 = every reference script; 200 = the class default, "
                     "mobile_env.py:37; the default run also reports G = 200 under other_grids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,11 +290,11 @@ class EnvRun:
     (main.py:205-211).  Before each segment the next CHUNK action rows are copied from the resident pool into a tape the
     graph / the multi-step kernel reads (3.3 MB device-to-device per 100 steps at 4096 envs)."""
 
-    def __init__(self, env, launch, pool):
+    def __init__(self, env, launch, pool, chunk=CHUNK):
         import torch
 
-        self.env, self.launch, self.pool = env, launch, pool
-        self.tape = torch.empty((CHUNK, env.n_envs), dtype=torch.int64, device=env.device)
+        self.env, self.launch, self.pool, self.chunk = env, launch, pool, int(chunk)
+        self.tape = torch.empty((self.chunk, env.n_envs), dtype=torch.int64, device=env.device)
         self.graphs = {}
         self.many_out = {}
         self.pk_out = {}
@@ -313,7 +325,7 @@ class EnvRun:
         t = self.t if t0 is None else t0
         segs = []
         while n_steps > 0:
-            n = min(CHUNK, n_steps, self.max_step - t)
+            n = min(self.chunk, n_steps, self.max_step - t)
             t += n
             n_steps -= n
             segs.append((n, t == self.max_step))
@@ -426,9 +438,10 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
     from drl_uav_cellularnet_amd.sharding import gather_over_ranks, max_over_ranks
 
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    n_pool = max(CHUNK, min(((K + W + CHUNK - 1) // CHUNK) * CHUNK, 5 * CHUNK))    # action pool resident in HBM, cycled
+    ck = int(args.chunk)
+    n_pool = max(ck, min(((K + W + ck - 1) // ck) * ck, 5 * max(ck, CHUNK)))    # action pool resident in HBM, cycled
     pool = torch.randint(0, min(env.action_space_dim, 2 ** 62), (n_pool, env.n_envs), generator=gen, dtype=torch.int64).to(dev)
-    r = EnvRun(env, launch, pool)
+    r = EnvRun(env, launch, pool, chunk=ck)
     sizes = [n for n, _ in r.plan(W)] + [n for n, _ in r.plan(K, t0=(r.t + W) % r.max_step)]
     r.prepare(sizes)
     if scratch is not None:
@@ -437,6 +450,15 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         # the clock ramp.  PREWARM_STEPS eager steps, untimed, immediately before the measured env's own W warm-up steps.
         for t in range(PREWARM_STEPS):
             scratch.step(pool[t % n_pool])
+        if launch in ("many", "manypk"):
+            # ... and the scratch env through the SAME launch form and call sizes as the measured one: a multi-step call of another size
+            # may take another code path of the kernel (a rotation schedule's pieces, section 4d), and the first execution of a path pays
+            # its instruction fetch from memory -- 20-30 us, which a 20-step timed region (0.1 ms) would otherwise carry
+            rs = EnvRun(scratch, launch, pool, chunk=ck)
+            rs.prepare(sizes)
+            for n in sorted(set(sizes)):
+                for _ in range(3):
+                    rs.run(n)
     r.run(W)
     r.stage(K)
     prog = r.compile(K)
@@ -457,8 +479,15 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         _capi.check(bad[0])
     per_rank = gather_over_ranks([elapsed, gpu_ms], device=reduce_dev)   # every rank's own clock: a straggler must be visible
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
+    sched = None
+    if launch in ("many", "manypk"):                                       # how the library runs a call of this many steps on this handle
+        import ctypes as C
+
+        nl, sl = C.c_int(0), C.c_longlong(0)
+        env._lib.uavenv_debug_rotation_info(env._h, min(ck, K), C.byref(nl), C.byref(sl))
+        sched = {"form": SCHEDULE_NAMES.get(min(nl.value, 2), "?"), "dispatches_per_call": max(1, nl.value), "wavefronts_per_dispatch": sl.value or None}
     return elapsed, gpu_ms, {"kernels": kernels, "per_rank_elapsed_s": [p[0] for p in per_rank],
-                             "per_rank_gpu_ms": [p[1] for p in per_rank]}
+                             "per_rank_gpu_ms": [p[1] for p in per_rank], "schedule": sched, "device_error": env.device_error()}
 
 
 def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollout_len=A2C_ROLLOUT):
@@ -491,7 +520,13 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
     per_rank = [p[0] for p in gather_over_ranks([elapsed], device=reduce_dev)]     # every rank's own clock (a straggler must be visible)
     elapsed = max_over_ranks([elapsed], device=reduce_dev)[0]
     n = envs * rollout_len * rollouts
-    st = runner.stats
+    st = dict(runner.stats)
+    roof = None
+    if True:                                                       # every rank: the extra update ends in the same collective(s) as a timed one
+        try:
+            roof = a2c_roofline(runner, envs, rollout_len)
+        except Exception as ex:                                    # an annotation: never a reason to lose the measurement
+            roof = {"error": "%s: %s" % (type(ex).__name__, ex)}
     ar_ms, ar_bytes = st.get("allreduce_ms"), grad_allreduce_bytes(runner.net)
     ov_ms, buckets = st.get("allreduce_overlapped_ms"), st.get("allreduce_buckets")
     f = 2.0 * (world - 1) / world
@@ -518,8 +553,94 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
                           else ("%s backend (rehearsal)" % args.backend if world > 1 else "none (1 rank)")),
             "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
             "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
+            "roofline": roof, "pipeline_halves": getattr(runner, "_halves", None) is not None,
             "config": "%d envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, %d-step rollouts, 1 update per rollout"
                       % (envs, rollout_len)}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # dense v_mfma_f32_16x16x4_f32 peak (MI355X_MICROARCH.md; the learner computes in float32 like the reference)
+GATHER_CACHE_TBPS = 8.6          # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows (Infinity Cache) 8.6 TB/s chip-wide
+GATHER_LARGE_TBPS = 7.9          # same table: 151 MB table, uniformly random rows 7.4-7.9 TB/s chip-wide (upper figure)
+
+
+def a2c_roofline(runner, envs, T):
+    """Per dominant learner kernel: time from HIP events around each launch of ONE extra eager rollout + update of this run
+    (_agent_capi.profile_begin / profile_end; the timed region itself replays a hipGraph and cannot be bracketed per kernel), its
+    algorithmic flops or bytes, the roof that bounds it and the achieved fraction.  Roofs: 157.3 TFLOP/s float32 MFMA; 8 TB/s HBM for
+    streaming kernels; for the two indexed-row kernels the fabric's gather rate the guide measured for a table of that size (both
+    cited in `roof_source`) -- their rows come out of the Infinity Cache / across the fabric, not out of HBM at its peak."""
+    import torch
+
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    N, H, NA, K = envs, 200, runner.net.n_action, runner.env.nBS + runner.env.nUE
+    M = N * T
+    was = runner.collect_launch
+    runner.collect_launch = "eager"
+    torch.cuda.synchronize()
+    A.profile_begin()
+    try:
+        batch = runner.collect()
+        runner.update(*batch)
+    finally:
+        times = A.profile_end()
+        runner.collect_launch = was
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    act = runner.act_buf[0]
+    e0.record()
+    for _ in range(T):
+        runner.env.step(act, reward_out=runner.rew_buf[0])
+    e1.record()
+    torch.cuda.synchronize()
+    env_us = e0.elapsed_time(e1) * 1e3 / T
+
+    def entry(keys, work, unit, roof, roof_src, what, calls_per_rollout):
+        ms = [m for k in keys for m in times.get(k, [])]
+        if not ms:
+            return None
+        avg_us = sum(ms) / len(ms) * 1e3
+        rate = work / (avg_us * 1e-6) / 1e12                     # TFLOP/s or TB/s
+        return {"what": what, "calls_per_rollout": calls_per_rollout, "avg_us": avg_us, "ms_per_rollout": avg_us * calls_per_rollout * 1e-3,
+                "work_per_call": work, "work_unit": "flop" if unit == "TFLOP/s" else "bytes", "achieved": rate, "unit": unit,
+                "peak": roof, "frac": rate / roof, "roof_source": roof_src, "launches_timed": len(ms)}
+
+    mfma = ("dense float32 MFMA peak (MI355X_MICROARCH.md)", MFMA_F32_PEAK_TFLOPS)
+    out = {}
+    rows = [
+        ("actor_head", ["uavagent_actor_head_f32[rows=%d]" % N], 2.0 * N * (H * H + H * NA), "TFLOP/s", mfma[1], mfma[0],
+         "rollout step: layer 2 + policy head + action draw, one kernel (main.py:147-150,165-169)", T),
+        ("first_layer_gather", ["uavagent_first_layer_from_obs_f32[rows=%d]" % N], float(N) * K * 2 * H * 4, "TB/s", GATHER_CACHE_TBPS,
+         "gather of 1 600-byte row pairs out of two 40 MB tables: MI355X_MICROARCH.md 'Indexed rows', 38 MB table 8.6 TB/s chip-wide",
+         "rollout step: first layer of both trunks from the compact observation (sum of B + U table rows per env)", T - 1),
+        ("table_gradient", ["uavagent_rows_grad_sums_f32[M=%d,K=%d]" % (M, K)], float(M) * K * 2 * H * 4, "TB/s", GATHER_LARGE_TBPS,
+         "gather of one 1 600-byte g row per (sample, index) pair from a 655 MB array: MI355X_MICROARCH.md 'Indexed rows', 151 MB table "
+         "7.4-7.9 TB/s chip-wide", "update: x^T g for the 0/1 first-layer input (both tables)", 1),
+        ("dW_policy_head", ["uavagent_gemm_tn_f32[M=%d,I=%d,J=%d]" % (M, H, NA)], 2.0 * M * H * NA, "TFLOP/s", mfma[1], mfma[0], "update: h2a^T dlogits", 1),
+        ("dW_200x200", ["uavagent_gemm_tn_f32[M=%d,I=%d,J=%d]" % (M, H, H)], 2.0 * M * H * H, "TFLOP/s", mfma[1], mfma[0], "update: two of them (actor, critic layer 2)", 2),
+        ("dX_policy_head", ["uavagent_gemm_rows_f32[M=%d,K=%d,N=%d,relu6_mask]" % (M, (NA + 15) // 16 * 16, H)], 2.0 * M * NA * H, "TFLOP/s", mfma[1], mfma[0],
+         "update: dlogits @ W3^T with the relu6 mask fused", 1),
+        ("dX_200x200", ["uavagent_gemm_rows_f32[M=%d,K=%d,N=%d,relu6_mask]" % (M, H, H)], 2.0 * M * H * H, "TFLOP/s", mfma[1], mfma[0],
+         "update: two of them, relu6 mask + bias gradient fused (W^T resident in LDS)", 2),
+        ("forward_critic_layer2", ["uavagent_gemm_rows_f32[M=%d,K=%d,N=%d,bias]" % (M, H, H)], 2.0 * M * H * H, "TFLOP/s", mfma[1], mfma[0],
+         "update: the one forward GEMM the rollout did not already compute", 1),
+        ("loss_grad", ["uavagent_a2c_loss_grad[M=%d,A=%d]" % (M, NA)], 2.0 * M * NA * 4, "TB/s", HBM_PEAK_GBPS / 1e3, "HBM peak (MI355X_MICROARCH.md)",
+         "update: softmax, entropy, both losses and d loss / d logits in one pass (logits read and overwritten)", 1),
+    ]
+    for name, keys, work, unit, roof, src, what, calls in rows:
+        e = entry(keys, work, unit, roof, src, what, calls)
+        if e is not None:
+            out[name] = e
+    b_step = algorithmic_bytes_per_env_step(runner.env.nUE, runner.env.nBS, int(runner.env.cfg.n_groups))
+    out["env_step"] = {"what": "rollout step: uavenv_step of all envs (the closed-loop form: one kernel per step)", "calls_per_rollout": T,
+                       "avg_us": env_us, "ms_per_rollout": env_us * T * 1e-3, "work_per_call": b_step * N, "work_unit": "bytes (SURVEY 8(d) algorithmic)",
+                       "achieved": b_step * N / (env_us * 1e-6) / 1e12, "unit": "TB/s", "peak": HBM_PEAK_GBPS / 1e3,
+                       "frac": b_step * N / (env_us * 1e-6) / 1e12 / (HBM_PEAK_GBPS / 1e3), "roof_source": "HBM peak (nominal, as the headline's roofline.frac)",
+                       "launches_timed": T}
+    covered = sum(v["ms_per_rollout"] for v in out.values())
+    return {"kernels": out, "ms_per_rollout_covered": covered,
+            "method": "HIP events around every launch of one extra EAGER rollout + update of this run (after the timed region); back-to-back launches "
+                      "on one stream, so a pair brackets its kernel plus ~2 us of launch gap; PMC passes of the same kernels: profiles/ (DESIGN 10c/10d)",
+            "all_launches_ms": {k: round(sum(v), 4) for k, v in sorted(times.items())}}
 
 
 def main(argv=None):
@@ -625,8 +746,9 @@ def main(argv=None):
         achieved = b_step * E / per_step_s / 1e9
         many = args.launch in ("many", "manypk")
         kernel = (info["kernels"] or ["?"])[0]                  # the instantiation the timed region launched (library's launch census)
-        spl = min(CHUNK, K) if many else 1                      # steps one launch of the dominant kernel processes
-        cnt = committed_counters(E, n_bs, n_ue, kernel)
+        spl = min(int(args.chunk), K) if many else 1            # steps one CALL of the step entry point processes
+        schedule = (info.get("schedule") or {}).get("form", "plain") if many else "plain"
+        cnt, why_not = committed_counters(E, n_bs, n_ue, kernel, spl, schedule)
         n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "achieved_is": "NOMINAL: SURVEY 8(d)'s algorithmic bytes per env-step x env-steps per launch / launch time, as the bench "
@@ -636,6 +758,7 @@ def main(argv=None):
                 "traffic": None, "traffic_source": None, "moved_bytes_per_step": None, "moved_GBps": None, "moved_frac": None,
                 "bound_actual": "valu_issue", "valu_issue_frac": None,
                 "kernel": kernel, "kernels_launched_in_timed_region": info["kernels"],
+                "schedule": info.get("schedule"), "traffic_unavailable_because": why_not,
                 "steps_per_launch": spl,
                 "algorithmic_bytes_per_env_step": b_step,
                 "algorithmic_bytes_per_launch": b_step * E * spl,
@@ -647,7 +770,7 @@ def main(argv=None):
             # FETCH_SIZE on gfx950 counts 64 B per 128-B request for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM):
             # every state load of these kernels is such a dwordx4 record load, hence the x2; WRITE_SIZE is exact.  The committed
             # figures are per launch of cnt["steps_per_launch"] steps; scaled to this run's steps per launch.
-            scale = spl / float(cnt["steps_per_launch"])
+            scale = 1.0                                      # (the entry IS this dispatch form: committed_counters matched steps per call and schedule)
             roof["traffic"] = int((2 * int(cnt["fetch_size_bytes_raw"]) + int(cnt["write_size_bytes_raw"])) * scale)
             roof["traffic_over_algorithmic"] = roof["traffic"] / float(b_step * E * spl)
             roof["traffic_source"] = ("profiles/traffic_current.json (%s): committed rocprofv3 PMC passes of this kernel at this batch size "

@@ -32,10 +32,66 @@ def lib_path():
     return os.environ.get("UAVAGENT_LIB") or _build.AGENT_LIB
 
 
+# ---- per-launch timing (bench.py: the learner's roofline figures) -----------------------------------------------------------------
+# profile_begin() makes load() hand out a proxy that brackets every launch entry point with HIP events on the current stream;
+# profile_end() synchronises and returns {key: [milliseconds per call]}.  Meant for EAGER passes (a replayed hipGraph makes no calls);
+# the kernels of one stream run one after the other, so an event pair measures the launch it brackets.  Off (the default): load()
+# returns the plain CDLL, nothing is added to any call.
+_prof = None
+_PROF_KEYS = {
+    # name -> indices of the integer arguments that tell two uses of one entry point apart
+    "uavagent_gemm_rows_f32": lambda a: "M=%d,K=%d,N=%d%s" % (a[5], a[6], a[7], ",relu6_mask" if a[10] else (",bias" if a[8] else "")),
+    "uavagent_gemm_tn_f32": lambda a: "M=%d,I=%d,J=%d" % (a[2], a[3], a[4]),
+    "uavagent_actor_head_f32": lambda a: "rows=%d" % a[6],
+    "uavagent_first_layer_from_obs_f32": lambda a: "rows=%d" % a[9],
+    "uavagent_sparse_rows_sum_f32": lambda a: "rows=%d" % a[7],
+    "uavagent_rows_grad_sums_f32": lambda a: "M=%d,K=%d" % (a[1], a[2]),
+    "uavagent_rows_grad_f32": lambda a: "M=%d,K=%d" % (a[2], a[3]),
+    "uavagent_a2c_loss_grad": lambda a: "M=%d,A=%d" % (a[5], a[6]),
+}
+
+
+class _ProfiledLib:
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.endswith(("_f32", "_grad", "_bwd", "_tf1", "_sort", "_indices", "_actions")) or name.endswith("_bytes"):
+            return fn
+
+        def timed(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            keyf = _PROF_KEYS.get(name)
+            key = name + ("[%s]" % keyf(args) if keyf else "")
+            if _prof is not None:
+                _prof.setdefault(key, []).append((e0, e1))
+            return rc
+        return timed
+
+
+def profile_begin():
+    global _prof
+    load()
+    _prof = {}
+
+
+def profile_end():
+    """-> {"entry point[shape]": [ms, ...]} for every launch since profile_begin() (synchronises the device)."""
+    global _prof
+    torch.cuda.synchronize()
+    out = {k: [a.elapsed_time(b) for a, b in v] for k, v in (_prof or {}).items()}
+    _prof = None
+    return out
+
+
 def load():
     global _lib
     if _lib is not None:
-        return _lib
+        return _ProfiledLib(_lib) if _prof is not None else _lib
     path = lib_path()
     if not os.path.isfile(path):
         raise UavAgentError("%s not found: run `python -m drl_uav_cellularnet_amd.build` (there is no fallback for CUDA "

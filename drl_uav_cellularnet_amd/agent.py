@@ -330,7 +330,7 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=False):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=True, force_exchange=False):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -357,6 +357,9 @@ class A2CRunner:
         # more than one rank: the critic trunk's gradient (40 MB, first half of the exchange) is all-reduced on a side stream while the
         # actor trunk's backward pass still runs (update_fused, hip_gemms path)
         self.overlap_allreduce = bool(overlap_allreduce)
+        # force_exchange (tests): run the gradient exchange -- the collective calls, the side stream, the bucket order -- even when the
+        # process group has ONE rank, so that a one-GPU box executes the call sequence an 8-GPU run starts with (backend nccl = RCCL)
+        self.force_exchange = bool(force_exchange)
         # fused_head: layer 2, the policy head and the action draw of a rollout step as ONE kernel (uavagent_actor_head_f32)
         self.fused_head = bool(fused_head) and self.hip_gemms and 576 < self.net.n_action <= 640
         # overlap_dw (one rank, hip_gemms): the three dW GEMMs (MFMA bound, 1.6 ms at config 3) run on a side stream beside the
@@ -372,22 +375,27 @@ class A2CRunner:
         self._side = None
         # pipeline_halves (GPU, fused_head + fused_obs): the workers of a2c_single_thread.py:113-118 are independent of each other for a
         # whole rollout, so the batch is cut in two halves that ping-pong on two streams inside the rollout (and inside its captured
-        # graph): while the actor's head of one half runs (MFMA / LDS-DMA bound, half the CUs), the other half steps its envs and
-        # gathers its first layer (fabric bound, no MFMA).  The two heads never overlap each other (events), which is what keeps the
-        # halves out of lockstep.  Same kernels on the same rows with the same uniforms: bit-identical to the unsplit rollout.
+        # graph): while the actor's head of one half runs (MFMA / LDS-DMA bound; 16-row workgroups, so that half a batch still gives
+        # every CU one), the other half steps its envs (uavenv_step_range) and gathers its first layer (fabric bound, no MFMA).  The
+        # two heads never overlap each other (events), which is what keeps the halves out of lockstep.  Same arithmetic per row with the
+        # same uniforms: bit-identical to the unsplit rollout.  Measured at 8192 envs x 50 steps, interleaved in one process
+        # (profiles/r04i_ab_collect_pipeline_forms.json): 4.40-4.46 ms per rollout against 5.04-5.17 unsplit; three or four parts, or
+        # no order between the heads, are slower (every cross-stream edge of the graph costs ~9 us, every node of a two-stream graph ~5).
         # True = when each half still fills the chip (>= 4096 envs), "force" = whenever the batch can be cut (tests).
         self._halves = None
-        self._pipe_stream = None
+        self._pipe_streams = []
         import os as _os
 
-        self.pipeline_mode = _os.environ.get("UAVAGENT_PIPE_MODE", "alternate")    # "alternate" | "stagger" (A/B runs: tools/ab_collect.py)
-        if pipeline_halves and self.dev.type == "cuda" and self.fused_head and self.fused_obs:
-            import math
-
-            unit = math.lcm(int(env.envs_per_wavefront), 32)          # env wavefronts and the head's 32-row tiles both stay whole
-            cut = (env.n_envs // 2 + unit - 1) // unit * unit
-            if 0 < cut < env.n_envs and (pipeline_halves == "force" or env.n_envs >= 4096):
-                self._halves = ((0, cut), (cut, env.n_envs))
+        # UAVAGENT_PIPE_MODE (A/B runs, tools/ab_collect.py): "alternate" = the parts' heads run one after the other (events), everything
+        # else free; "free" = no cross-stream order at all; "stagger" = free, but part p starts p gathers late.  UAVAGENT_PIPE_PARTS: 2..8.
+        self.pipeline_mode = _os.environ.get("UAVAGENT_PIPE_MODE", "alternate")
+        n_parts = int(_os.environ.get("UAVAGENT_PIPE_PARTS", "2"))
+        if pipeline_halves and self.dev.type == "cuda" and self.fused_head and self.fused_obs and 2 <= n_parts <= 8:
+            unit = 16                                                 # the head's 16-row tiles stay whole (a part of a batch runs on 16-row
+            per = (env.n_envs // n_parts + unit - 1) // unit * unit   #  workgroups: 8192 envs = 2 x 256 tiles = one workgroup per CU and half)
+            cuts = [min(i * per, env.n_envs) for i in range(n_parts)] + [env.n_envs]
+            if all(cuts[i] < cuts[i + 1] for i in range(n_parts)) and (pipeline_halves == "force" or env.n_envs >= 4096):
+                self._halves = tuple((cuts[i], cuts[i + 1]) for i in range(n_parts))
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
         # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
@@ -489,50 +497,55 @@ class A2CRunner:
                 self._indices_into(self.idx_buf[t + 1])
 
     def _rollout_steps_pipelined(self):
-        """The T-step loop with the batch cut in two halves on two streams (see pipeline_halves in __init__).  Per half and step:
-        first layer from the observation the half's previous step left (gather), actor head, env step of the half's envs
-        (uavenv_step_range).  Cross-stream order: head(B, t) after head(A, t), head(A, t + 1) after head(B, t).  Capturable: the
-        second stream forks from and joins the calling stream through events."""
+        """The T-step loop with the batch cut in parts, one stream each (see pipeline_halves in __init__).  Per part and step: first
+        layer from the observation the part's previous step left (gather), actor head, env step of the part's envs
+        (uavenv_step_range).  Cross-stream order in mode "alternate": head(part p, step t) after head(part p - 1, t), head(part 0, t + 1)
+        after head(last part, t).  Capturable: the extra streams fork from and join the calling stream through events."""
         from . import _agent_capi as A
 
         env, T, net, fw, wt = self.env, self.T, self.net, self._fwd, self._wt
         self.idx_buf[0].copy_(self.idx_buf[T])
         main = torch.cuda.current_stream(self.dev)
-        if self._pipe_stream is None:
-            self._pipe_stream = torch.cuda.Stream(device=self.dev)
-        side = self._pipe_stream
+        P = len(self._halves)
+        while len(self._pipe_streams) < P - 1:
+            self._pipe_streams.append(torch.cuda.Stream(device=self.dev))
+        streams = [main] + self._pipe_streams[:P - 1]
         fork = torch.cuda.Event()
         fork.record(main)
-        side.wait_event(fork)
+        for st in streams[1:]:
+            st.wait_event(fork)
         obs = env.observation()
-        head_done = [None, None]
-        alternate = self.pipeline_mode == "alternate"
+        alternate, stagger = self.pipeline_mode == "alternate", self.pipeline_mode == "stagger"
+        last_head = None                                              # event behind the head issued last (mode "alternate")
+        first_gather = [None] * P
         for t in range(T):
-            for h, ((lo, hi), st) in enumerate(zip(self._halves, (main, side))):
+            for h, ((lo, hi), st) in enumerate(zip(self._halves, streams)):
                 with torch.cuda.stream(st):
-                    if t == 0 and h == 1 and not alternate:          # "stagger": the second half starts one gather late, then runs free
-                        st.wait_event(first_gather)
+                    if t == 0 and h > 0 and stagger:                 # part h starts when part h - 1 has done its first gather, then runs free
+                        st.wait_event(first_gather[h - 1])
                     if t == 0:
                         A.sparse_rows_sum(self.idx_buf[0][lo:hi], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][0][lo:hi],
                                           out_c=fw["h1c"][0][lo:hi])
+                        if stagger:
+                            first_gather[h] = torch.cuda.Event()
+                            first_gather[h].record(st)
                     else:
                         A.first_layer_from_obs({k: v[lo:hi] for k, v in obs.items()}, self.G, net.a_w1, net.a_b1, net.c_w1, net.c_b1,
                                                fw["h1a"][t][lo:hi], fw["h1c"][t][lo:hi], idx_out=self.idx_buf[t][lo:hi])
-                    if t == 0 and h == 0 and not alternate:
-                        first_gather = torch.cuda.Event()
-                        first_gather.record(st)
-                    if alternate and head_done[1 - h] is not None:
-                        st.wait_event(head_done[1 - h])              # the two heads alternate; everything else overlaps them
+                    if alternate and last_head is not None:
+                        st.wait_event(last_head)                     # the heads run one after the other; everything else overlaps them
                     A.actor_head(fw["h1a"][t][lo:hi], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf[t][lo:hi], net.n_action,
                                  fw["h2a"][t][lo:hi], self._logits_pad[t][lo:hi], self.act_buf[t][lo:hi])
-                    head_done[h] = torch.cuda.Event()
-                    head_done[h].record(st)
+                    if alternate:
+                        last_head = torch.cuda.Event()
+                        last_head.record(st)
                     env.step_range(self.act_buf[t], lo, hi - lo, reward_out=self.rew_buf[t])
                     if t == T - 1:
                         A.obs_indices({k: v[lo:hi] for k, v in obs.items()}, self.G, self.B, out=self.idx_buf[T][lo:hi])
-        join = torch.cuda.Event()
-        join.record(side)
-        main.wait_event(join)
+        for st in streams[1:]:
+            join = torch.cuda.Event()
+            join.record(st)
+            main.wait_event(join)
 
     @torch.no_grad()
     def collect(self):
@@ -616,7 +629,7 @@ class A2CRunner:
         backward pass wrote; the 1 / world_size is folded into the optimiser step.  -> (elements reduced, g_scale)."""
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force_exchange):
             return self.flat.n_real, 1.0
         if self.flat.g.is_cuda and dist.get_backend() == "gloo":      # rehearsal on a one-GPU box (several ranks share the
             host = self.flat.g.cpu()                                  # card, RCCL refuses that): reduce through the host
@@ -631,6 +644,14 @@ class A2CRunner:
         import torch.distributed as dist
 
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _exchanging(self):
+        """True when an update ends in a collective: more than one rank, or force_exchange with an initialised process group."""
+        import torch.distributed as dist
+
+        if self._world() > 1:
+            return True
+        return self.force_exchange and dist.is_available() and dist.is_initialized()
 
     def _allreduce_bucket(self, lo, hi, async_op=False):
         """Sum of flat.g[lo:hi] over ranks, in place.  nccl (RCCL): returns the work handle when async_op; gloo with CUDA tensors (the
@@ -669,7 +690,7 @@ class A2CRunner:
             self._upd.update({"w3p": torch.zeros((H, ldl), dtype=torch.float32, device=dev),       # a_w3 in rows of ldl, zero tail
                               "ws_tn_h": A.gemm_tn_workspace(M, H, dev), "ws_tn_a": A.gemm_tn_workspace(M, NA, dev),
                               "ws_cs": A.gemm_rows_workspace(M, dev)})
-            if self._world() > 1 and self.overlap_allreduce:     # one table gradient per trunk: each needs its g rows contiguous
+            if self._exchanging() and self.overlap_allreduce:    # one table gradient per trunk: each needs its g rows contiguous
                 self._upd.update({"g_a": f(M, H), "g_c": f(M, H)})
             elif self.overlap_dw:                                # the critic's dh2 beside the actor's: both outlive the dX chain
                 self._upd["dh_c"] = f(M, H)

@@ -223,7 +223,7 @@ class BatchedMobiEnv:
 
     @property
     def envs_per_wavefront(self):
-        """Env instances one wavefront of the step kernel hosts (ranges of step_range start and end on multiples of it)."""
+        """Env instances one wavefront of the step kernel hosts."""
         packed = self.nUE <= 64 and self.nUE >= self.nBS and self.nUE >= int(self.cfg.n_groups)
         return min(64 // self.nUE, 8) if packed else 1
 

@@ -1099,16 +1099,24 @@ __global__ __launch_bounds__(kRsThr, 1) void gemm_rows_resident_kernel(const flo
 // Two stages of 320 policy columns against three of 256: 33.5 against 34 us for a lone workgroup, 38.9 us at 8192 rows either way -- the
 // prefetch distance was not what the boundaries cost; a workgroup issues 84 LDS-DMA instructions per wave for its 672 KB of weights.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kHdRows = 32, kHdH = 200, kHdNP = 640, kHdWaves = 8, kHdThr = kHdWaves * 64;
-constexpr int kHdH1F4 = kHdRows * kHdH / 4, kHdH1Pass = (kHdH1F4 + kHdThr - 1) / kHdThr;         // 1600 float4: 4 passes (the last one: 1 wave)
+// RB = 16-row blocks per workgroup: 2 (32 rows, wave = row block w & 1 x column quarter w >> 1) for a whole rollout batch -- 8192 rows are one
+// workgroup per CU --, 1 (16 rows, wave = column eighth w) for HALF a batch, so that it still spreads over every CU (A2CRunner(pipeline_halves)):
+// the time of a workgroup is mostly its stream of W2^T + W3^T (672 KB) and does not shrink with the number of workgroups.
+constexpr int kHdH = 200, kHdNP = 640, kHdWaves = 8, kHdThr = kHdWaves * 64;
 constexpr int kHdW2Rows = 256, kHdW2Pass = kHdW2Rows * 10 / kHdThr;                              // 2560 float4: 5 passes
 constexpr int kHdW3Rows = 320;                                                                  // (rows of a phase-1 ring stage: 256 used)
 constexpr int kHdStageF = kHdW3Rows * kGlBK;                                                    // 12 800 floats per ring stage (phase 1's two)
 constexpr int kHdPartRows = 256, kHdP3StageF = kHdPartRows * kGlBK, kHdP3Pass = kHdPartRows * 10 / kHdThr;   // phase 2: 10 240 floats per stage, 5 passes
-constexpr int kHdLdsF = 2 * kHdRows * kHdH + 2 * kHdStageF;                                     // 38 400 floats = 153 600 B
-static_assert(kHdW2Rows * kGlBK <= kHdStageF && kHdH1F4 % 64 == 0 && 3 * kHdP3StageF <= kHdRows * kHdH + 2 * kHdStageF &&
-              kHdRows * kHdNP <= kHdRows * kHdH + 2 * kHdStageF && kHdPartRows * 10 % kHdThr == 0 && (kHdNP - 2 * kHdPartRows) * 10 % 64 == 0 &&
-              kHdNP - 2 * kHdPartRows == 128, "the head's LDS plan");
+// LDS: [h2 tile | h1 tile | ring]; phase 2 reuses [h1 tile | ring] as a three-stage ring and then as the logits tile
+template <int RB> struct HdPlan {
+    static constexpr int Rows = 16 * RB, H1F4 = Rows * kHdH / 4, H1Pass = (H1F4 + kHdThr - 1) / kHdThr;
+    static constexpr int RingF = (2 * kHdStageF > 3 * kHdP3StageF - Rows * kHdH) ? 2 * kHdStageF : 3 * kHdP3StageF - Rows * kHdH;
+    static constexpr int LdsF = 2 * Rows * kHdH + RingF;                                   // RB = 2: 38 400 floats = 153 600 B; RB = 1: 33 920 = 135 680 B
+    static constexpr int CQ = 8 / RB, NCB1 = 16 / CQ, NCBC = 8 / CQ;                       // column groups; column blocks per wave in layer 2 / parts A, B and in part C
+    static_assert(kHdW2Rows * kGlBK <= kHdStageF && 3 * kHdP3StageF <= Rows * kHdH + RingF && Rows * kHdNP <= Rows * kHdH + RingF &&
+                  kHdPartRows * 10 % kHdThr == 0 && (kHdNP - 2 * kHdPartRows) * 10 % 64 == 0 && kHdNP - 2 * kHdPartRows == 128 && LdsF * 4 <= 160 * 1024 &&
+                  Rows % kHdWaves == 0 && (Rows * kHdNP / 4) % kHdThr == 0, "the head's LDS plan");
+};
 
 __device__ __forceinline__ float wave_max_g(float v) {
 #pragma unroll
@@ -1147,17 +1155,20 @@ __device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int
     }
 }
 
+template <int RB>
 __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
                                                                 const float *__restrict__ w3t, const float *__restrict__ b3p,
                                                                 const float *__restrict__ uni, long long n_rows, int n_act,
                                                                 float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
                                                                 long long *__restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[kHdLdsF];
+    using P = HdPlan<RB>;
+    constexpr int kHdRows = P::Rows, kHdH1F4 = P::H1F4, kHdH1Pass = P::H1Pass, NCB1 = P::NCB1, NCBC = P::NCBC;
+    __shared__ __attribute__((aligned(16))) float lds[P::LdsF];
     // [h2 tile | h1 tile | ring]: the policy head (phase 2) no longer needs h1 and runs a THREE-stage ring over [h1 tile | ring]
     float *const sH2 = lds, *const sH1 = lds + kHdRows * kHdH, *const ring = lds + 2 * kHdRows * kHdH;
     float *const ring3 = sH1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, q = lane >> 4, rb = wave & 1, qt = wave >> 1;          // row block, column quarter
+    const int r = lane & 15, q = lane >> 4, rb = (RB == 2) ? (wave & 1) : 0, qt = (RB == 2) ? (wave >> 1) : wave;   // row block, column group
     const long long m0 = (long long)blockIdx.x * kHdRows;
     using set0_t = std::integral_constant<int, 0>;
     using set1_t = std::integral_constant<int, 1>;
@@ -1173,7 +1184,8 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             if (slot * 64 < kHdH1F4) {
                 const int idx = slot * 64 + lane;
                 const float *g = (idx < lim) ? g0 + idx * 4 : g_zero16;
-                __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sH1 + slot * 256), 16, 0, 0);
+                if (kHdH1F4 % 64 == 0 || idx < kHdH1F4)          // (RB = 1: the tile ends inside the last slot; the lanes beyond it would write into the ring)
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sH1 + slot * 256), 16, 0, 0);
             }
         }
     }
@@ -1200,22 +1212,22 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     issue2(set0_t{}, 0);
 
     // ---- phase 1: h2 = relu6(h1 @ W2 + b2): wave = 16 rows x 4 of 16 column blocks (13 real) ----
-    f32x4 acc1[4];
+    f32x4 acc1[NCB1];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCB1; ++c) acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *pa1 = sH1 + (rb * 16 + r) * kHdH;
     auto chunk2 = [&](auto set_c, int c) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < 5) issue2(set_c, c + 1);
-        head_chunk<4>(pa1 + c * kGlBK, ring + (c & 1) * kHdStageF + (qt * 4 * 16 + r) * kGlBK, q, acc1);
+        head_chunk<NCB1>(pa1 + c * kGlBK, ring + (c & 1) * kHdStageF + (qt * NCB1 * 16 + r) * kGlBK, q, acc1);
     };
     chunk2(set1_t{}, 0); chunk2(set0_t{}, 1); chunk2(set1_t{}, 2); chunk2(set0_t{}, 3); chunk2(set1_t{}, 4);
     // bias + relu6 -> the h2 tile in LDS (row = m, k-contiguous: the A operand of the policy head)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int col = (qt * 4 + cb) * 16 + r;
+    for (int cb = 0; cb < NCB1; ++cb) {
+        const int col = (qt * NCB1 + cb) * 16 + r;
         if (col < kHdH) {
             const float bv = b2[col];
 #pragma unroll
@@ -1262,10 +1274,11 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         }
     }
     issue3(set1_t{}, 1);
-    f32x4 accA[4], accB[4], accC[2];
+    f32x4 accA[NCB1], accB[NCB1], accC[NCBC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { accA[c] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    accC[0] = f32x4{0.f, 0.f, 0.f, 0.f}; accC[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NCB1; ++c) { accA[c] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int c = 0; c < NCBC; ++c) accC[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *pa2 = sH2 + (rb * 16 + r) * kHdH;
     // chunk p3 has landed once at most the loads of chunk p3 + 1 are outstanding (5 per wave; in part 2: 3 for waves 0-3, 2 for the others)
     auto land3 = [&](int p3) {
@@ -1282,8 +1295,8 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         if (p3 + 2 < 15) issue3(set_c, p3 + 2);       // its stage was read last in chunk p3 - 1: every wave is past that
         head_chunk<NCB>(pa2 + (p3 % 5) * kGlBK, ring3 + (p3 % 3) * kHdP3StageF + (qt * NCB * 16 + r) * kGlBK, q, acc);
     };
-    using n4_t = std::integral_constant<int, 4>;
-    using n2_t = std::integral_constant<int, 2>;
+    using n4_t = std::integral_constant<int, NCB1>;      // column blocks of a wave in parts A and B ...
+    using n2_t = std::integral_constant<int, NCBC>;      // ... and in part C
     chunk3(set0_t{}, n4_t{}, 0, accA); chunk3(set1_t{}, n4_t{}, 1, accA); chunk3(set0_t{}, n4_t{}, 2, accA); chunk3(set1_t{}, n4_t{}, 3, accA); chunk3(set0_t{}, n4_t{}, 4, accA);
     chunk3(set1_t{}, n4_t{}, 5, accB); chunk3(set0_t{}, n4_t{}, 6, accB); chunk3(set1_t{}, n4_t{}, 7, accB); chunk3(set0_t{}, n4_t{}, 8, accB); chunk3(set1_t{}, n4_t{}, 9, accB);
     chunk3(set0_t{}, n2_t{}, 10, accC); chunk3(set1_t{}, n2_t{}, 11, accC); chunk3(set0_t{}, n2_t{}, 12, accC); chunk3(set1_t{}, n2_t{}, 13, accC); chunk3(set0_t{}, n2_t{}, 14, accC);
@@ -1292,8 +1305,8 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     // ---- phase 3: + bias -> logits tile in LDS; coalesced store; one wave samples 4 rows ----
     float *sL = ring3;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int colA = (qt * 4 + cb) * 16 + r, colB = kHdPartRows + colA;
+    for (int cb = 0; cb < NCB1; ++cb) {
+        const int colA = (qt * NCB1 + cb) * 16 + r, colB = kHdPartRows + colA;
         const float bA = b3p[colA], bB = b3p[colB];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1302,8 +1315,8 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int colC = 2 * kHdPartRows + (qt * 2 + cb) * 16 + r;
+    for (int cb = 0; cb < NCBC; ++cb) {
+        const int colC = 2 * kHdPartRows + (qt * NCBC + cb) * 16 + r;
         const float bC = b3p[colC];
 #pragma unroll
         for (int t = 0; t < 4; ++t) sL[(rb * 16 + 4 * q + t) * kHdNP + colC] = accC[cb][t] + bC;
@@ -1312,7 +1325,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     {
         const int rows = (int)(n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows);
 #pragma unroll 5
-        for (int i = 0; i < kHdRows * kHdNP / 4 / kHdThr; ++i) {                  // 5120 float4 over 512 threads
+        for (int i = 0; i < kHdRows * kHdNP / 4 / kHdThr; ++i) {                  // 5120 (2560) float4 over 512 threads
             const int idx = tid + kHdThr * i, row = idx / (kHdNP / 4), c4 = idx - row * (kHdNP / 4);
             if (row < rows) *reinterpret_cast<float4 *>(logits + (m0 + row) * ldl + c4 * 4) = *reinterpret_cast<const float4 *>(sL + row * kHdNP + c4 * 4);
         }
@@ -1561,33 +1574,6 @@ extern "C" int uavagent_gemm_tn_f32(const float *a, const float *b, int64_t m_ro
     return UAVAGENT_OK;
 }
 
-extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
-                                       const float *uniforms, int64_t n_rows, int32_t n_hidden, int32_t n_actions, float *h2_out,
-                                       float *logits_out, int64_t ld_logits, int64_t *actions_out, void *stream) {
-    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out)
-        return fail3(UAVAGENT_E_INVALID, "actor_head: null pointer");
-    if (n_hidden != kHdH || n_actions <= 576 || n_actions > kHdNP || ld_logits < kHdNP || (ld_logits & 3) || n_rows < 0)
-        return fail3(UAVAGENT_E_INVALID, "actor_head: built for 200 hidden units and 577..640 actions (the reference's 625 = 5^4; 10 policy columns "
-                                         "per lane, like uavagent_sample_actions at that width), ld_logits >= 640 and a multiple of 4");
-    if (!aligned16(h1) || !aligned16(w2t) || !aligned16(w3t_padded) || !aligned16(h2_out) || !aligned16(logits_out))
-        return fail3(UAVAGENT_E_INVALID, "actor_head: matrices must be 16-byte aligned");
-    if (n_rows == 0) return UAVAGENT_OK;
-    hipLaunchKernelGGL(actor_head_kernel, dim3((unsigned)((n_rows + kHdRows - 1) / kHdRows)), dim3(kHdThr), 0, (hipStream_t)stream, h1, w2t, b2, w3t_padded,
-                       b3_padded, uniforms, (long long)n_rows, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
-                       reinterpret_cast<long long *>(actions_out));
-    if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head: launch failed");
-    return UAVAGENT_OK;
-}
-
-extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
-    if (m_rows < 1) return 0;
-    size_t b = (size_t)((m_rows + 63) / 64) * kNP * sizeof(float);          // one partial row per workgroup of the 64-row kernels (the most)
-#ifdef UAVGEMM_STAMPS
-    b += (size_t)((m_rows + 63) / 64) * 4 * 6 * sizeof(unsigned long long);
-#endif
-    return b;
-}
-
 // CU count of the CURRENT device (the caller has made the operands' device current), read once per device ordinal.
 static int cu_count_of_current_device() {
     static std::atomic<int> cache[64];
@@ -1599,6 +1585,44 @@ static int cu_count_of_current_device() {
         cache[dev].store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
+                                       const float *uniforms, int64_t n_rows, int32_t n_hidden, int32_t n_actions, float *h2_out,
+                                       float *logits_out, int64_t ld_logits, int64_t *actions_out, void *stream) {
+    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out)
+        return fail3(UAVAGENT_E_INVALID, "actor_head: null pointer");
+    if (n_hidden != kHdH || n_actions <= 576 || n_actions > kHdNP || ld_logits < kHdNP || (ld_logits & 3) || n_rows < 0)
+        return fail3(UAVAGENT_E_INVALID, "actor_head: built for 200 hidden units and 577..640 actions (the reference's 625 = 5^4; 10 policy columns "
+                                         "per lane, like uavagent_sample_actions at that width), ld_logits >= 640 and a multiple of 4");
+    if (!aligned16(h1) || !aligned16(w2t) || !aligned16(w3t_padded) || !aligned16(h2_out) || !aligned16(logits_out))
+        return fail3(UAVAGENT_E_INVALID, "actor_head: matrices must be 16-byte aligned");
+    if (n_rows == 0) return UAVAGENT_OK;
+    // 32-row workgroups while they give every CU one (a whole rollout batch of 8192 rows on 256 CUs); 16-row workgroups for fewer rows (half a
+    // batch on its own stream): the time of a workgroup is its weight stream, so fewer, larger workgroups would only leave CUs idle
+    const char *force_env = getenv("UAVAGENT_HEAD_RB");          // tests / A-B runs: 1 or 2 forces the tile height (read per call)
+    const int force_rb = force_env ? atoi(force_env) : 0;
+    const int n_cu = cu_count_of_current_device();
+    const bool small = force_rb ? (force_rb == 1) : (n_rows <= 24ll * n_cu);
+    if (small)
+        hipLaunchKernelGGL(actor_head_kernel<1>, dim3((unsigned)((n_rows + 15) / 16)), dim3(kHdThr), 0, (hipStream_t)stream, h1, w2t, b2, w3t_padded,
+                           b3_padded, uniforms, (long long)n_rows, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
+                           reinterpret_cast<long long *>(actions_out));
+    else
+        hipLaunchKernelGGL(actor_head_kernel<2>, dim3((unsigned)((n_rows + 31) / 32)), dim3(kHdThr), 0, (hipStream_t)stream, h1, w2t, b2, w3t_padded,
+                           b3_padded, uniforms, (long long)n_rows, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
+                           reinterpret_cast<long long *>(actions_out));
+    if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head: launch failed");
+    return UAVAGENT_OK;
+}
+
+extern "C" size_t uavagent_gemm_rows_workspace_bytes(int64_t m_rows) {
+    if (m_rows < 1) return 0;
+    size_t b = (size_t)((m_rows + 63) / 64) * kNP * sizeof(float);          // one partial row per workgroup of the 64-row kernels (the most)
+#ifdef UAVGEMM_STAMPS
+    b += (size_t)((m_rows + 63) / 64) * 4 * 6 * sizeof(unsigned long long);
+#endif
+    return b;
 }
 
 // UAVAGENT_ROWS_RESIDENT=0 (read once): the update's K = 200 GEMMs on version 4's 128-row workgroups instead of the resident-W kernel (A/B runs)

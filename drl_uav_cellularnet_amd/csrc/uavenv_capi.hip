@@ -418,16 +418,16 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     // (n_range > 0: envs [first_env, first_env + n_range) only -- uavenv_step_range has checked that the range starts on a wavefront
     //  boundary and ends on one or at N)
     KParams p = p_in;
-    const long long n_here = n_range > 0 ? n_range : p.N;
-    const long long waves = (n_here + p.epw - 1) / p.epw;
-    const int wave0 = (int)(first_env / p.epw);
-    p.wave0 = wave0; p.e_end = n_range > 0 ? first_env + n_range : p.N;
+    const long long e_lo = n_range > 0 ? first_env : 0, e_hi = n_range > 0 ? first_env + n_range : p.N;
+    const int wave0 = (int)(e_lo / p.epw);                                   // first env-wavefront with an env of the range
+    const long long waves = (e_hi + p.epw - 1) / p.epw - wave0;              // ... through the last one (either may straddle the range's border)
+    p.wave0 = wave0; p.e_end = e_hi;
     // (a launch of a rotation schedule has `launch_waves` slots instead of one wavefront per env-wavefront; p.sched says who does what)
     const unsigned grid = (unsigned)(((launch_waves > 0 ? launch_waves : waves) + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 blk(64 * kWavesPerBlock);
     // leading scalar arguments of the packed kernels: delivered in SGPRs at wave launch (kernarg preload), see
     // env_kernel_packed.  The slab base replaces the 19 per-field pointers (state_layout.h).
-#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), wave0, (n_range > 0 ? wave0 + (int)waves : 0), p
+#define PK_ARGS h->blob, p.actions, p.gid_of_u, p.N, p.U, p.epw, p.Gr, p.B, (int)uavk::lane_div_magic((uint32_t)p.U), wave0, (int)e_lo, (int)e_hi, p
     if (MODE == MODE_WARMUP) {
         // mobility only: independent of B / path loss, so one instantiation per kernel family
         const bool fast = !p.inj_theta && !p.inj_group && (p.B == 4);   // the warm-up instantiation has BT = 4
@@ -456,6 +456,10 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     // argument above is about materialising constants once per LAUNCH, which a 100-step launch amortises).
     // (a rotation schedule launches S = k x SIMDs slots for its W > S env-wavefronts: the wavefronts that are resident count)
     if (MANY) pin = fast && ((launch_waves > 0 ? launch_waves : waves) <= 2 * h->n_simd);
+    // A RANGE launch exists to run beside other kernels of the caller (the A2C rollout's other half: an MFMA workgroup of 8 wavefronts x 128
+    // VGPRs per CU).  The pinned variant's 251 VGPRs per wavefront leave no SIMD with two of them room for that workgroup, which then starts
+    // only when the env launch drains (rocprofv3 timeline, profiles/r04g_*): ranges run unpinned (90 VGPRs).
+    if (n_range > 0) pin = false;
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
@@ -546,10 +550,8 @@ extern "C" int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnv
 extern "C" int uavenv_step_range(uavenv_t *h, const int64_t *actions_dev, int64_t first_env, int64_t n_envs, const UavEnvInject *inj,
                                  const UavEnvOut *out, void *stream) {
     if (!h || !actions_dev) return fail(UAVENV_E_INVALID, "step_range: null handle or actions");
-    const long long epw = h->kp.epw;
-    if (first_env < 0 || n_envs < 1 || first_env + n_envs > h->N || first_env % epw != 0 || ((first_env + n_envs) % epw != 0 && first_env + n_envs != h->N))
-        return fail(UAVENV_E_INVALID, "step_range: the range must lie inside the batch, start on a multiple of " + std::to_string(epw) +
-                                      " envs (one wavefront hosts that many) and end on one or at n_envs");
+    if (first_env < 0 || n_envs < 1 || first_env + n_envs > h->N || h->N > 0x7FFFFFFFll)
+        return fail(UAVENV_E_INVALID, "step_range: the range must be non-empty and lie inside the batch");
     DeviceGuard guard(h->device);
     if (int rc_dev = poisoned(h, "step_range")) return rc_dev;
     KParams p = h->kp;

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, bool PKO>
 __device__ __forceinline__ void env_packed_body(char *blob, const long long *actions, const int8_t *gid_of_u, long long N, int U, int EPW,
                                                 int Gr, int B_rt, int lane_magic, const KParams &p, int (*s_bs)[kMaxEpw][2 * kMaxBs],
-                                                const int wave, const long long ew, const int t0, const int nt) {
+                                                const int wave, const long long ew, const int t0, const int nt, const int e_lo, const int e_hi) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
@@ -724,7 +724,9 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
     const int base = slot * U;   // first lane of my slot
     const int ul = lane - base;  // walker index inside the env (also: group / UAV index for owner lanes)
     long long e = ew * EPW + slot;
-    bool live = (lane < EPW * U) && (e < N);
+    // envs [e_lo, e_hi) of the batch: the whole batch (0, N), or a range of uavenv_step_range -- which need not start or end on a wavefront
+    // boundary: the wavefront that straddles a boundary runs in both launches, each with its own envs live
+    bool live = (lane < EPW * U) && (e >= e_lo) && (e < e_hi);
     if (is_reset(MODE)) { if (p.mask != nullptr) live = live && (p.mask[live ? e : 0] != 0); }
     if (__ballot(live) == 0ull) return;
     if (!live) e = 0;            // keep addresses in range; every store below is guarded by `live`
@@ -1041,7 +1043,7 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
-                                                                              int Gr, int B_rt, int lane_magic, int wave0, int wave_end, const KParams p) {
+                                                                              int Gr, int B_rt, int lane_magic, int wave0, int e_lo, int e_hi, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
     static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
@@ -1051,9 +1053,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // this wavefront's env-wavefront (uniform).  wave0 > 0: a launch over a RANGE of the batch (uavenv_step_range: envs wave0 * EPW ...)
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave + wave0;
-    if (wave0 != 0 || wave_end != 0) { if (gw >= wave_end) return; }   // a range launch: the last workgroup's surplus wavefronts belong to the next range
     if (!MANY) {
-        env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1);
+        env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1, e_lo, e_hi);
     } else {
         // Multi-step launch.  Plain: wavefront w hosts env-wavefront w for all p.n_ticks steps.  Rotation schedule (p.sched,
         // uavenv_capi.hip: rotation_plan): this wavefront is a SLOT that works through up to three pieces, each a run of consecutive
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         // pinned kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
         const int4 *sched = p.sched;
         if (sched == nullptr) {
-            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks);
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks, e_lo, e_hi);
             return;
         }
         // One-launch schedule: this wavefront is a SLOT with up to kSchedPieces pieces.  A piece that starts inside a job (SCHED_WAIT)
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             if (nt <= 0) continue;
             if (q > 0) __builtin_amdgcn_wave_barrier();                       // (the previous piece's reads of the LDS row are done)
             if (bits & SCHED_WAIT) { if (!sched_hand_off_wait(p, ew)) return; }
-            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt);
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt, e_lo, e_hi);
             if (bits & SCHED_PUBLISH) sched_hand_off_publish(p, ew);
         }
     }

@@ -131,9 +131,9 @@ int uavenv_step(uavenv_t *h, const int64_t *actions_dev, const UavEnvInject *inj
 
 /* The same step for the envs [first_env, first_env + n_envs) of the batch only (all pointers are still those of the WHOLE batch: the
  * kernel indexes them by env).  For callers that pipeline parts of a batch on several streams -- the A2C rollout steps one half
- * while the policy network works on the other (a2c_single_thread.py:113-118: the workers are independent of each other).  The
- * range must start on a multiple of the envs one wavefront hosts (floor(64 / n_ue) when n_ue <= 64 and n_ue >= n_bs, n_groups; else 1)
- * and end on one or at n_envs: UAVENV_E_INVALID otherwise.  Ranges that do not overlap may run concurrently. */
+ * while the policy network works on the other (a2c_single_thread.py:113-118: the workers are independent of each other).  Any
+ * non-empty range inside the batch (a wavefront whose envs straddle a range border runs in both launches, each with its own envs
+ * live); ranges that do not overlap may run concurrently on different streams. */
 int uavenv_step_range(uavenv_t *h, const int64_t *actions_dev, int64_t first_env, int64_t n_envs, const UavEnvInject *inj,
                       const UavEnvOut *out, void *stream);
 /* n_steps consecutive MobiEnvironment.step calls (mobile_env.py:150-194) in ONE launch, for callers whose actions do not depend on

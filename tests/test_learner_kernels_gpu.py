@@ -439,13 +439,16 @@ def test_gemm_rows_every_tile_shape_and_epilogue(shape):
         assert float((cs.double() - wm.sum(dim=0)).abs().max()) < 1e-5 * max(1.0, float(wm.abs().sum(dim=0).max()))
 
 
-@pytest.mark.parametrize("n_rows", [8192, 33, 1000])
-def test_actor_head_kernel_equals_the_three_launches(n_rows):
+@pytest.mark.parametrize("tile", ["auto", "1", "2"], ids=["tile_auto", "16_row_tiles", "32_row_tiles"])
+@pytest.mark.parametrize("n_rows", [8192, 33, 1000, 4128])
+def test_actor_head_kernel_equals_the_three_launches(n_rows, tile, monkeypatch):
     """uavagent_actor_head_f32 (layer 2 + policy head + inverse-CDF draw in one kernel, a workgroup per 32 rows) against
     uavagent_gemm_rows_f32 twice + uavagent_sample_actions: h2, logits (incl. the zero tail) and actions bit for bit, and against float64."""
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
 
+    if tile != "auto":                                  # both workgroup shapes at every size (auto: 16-row tiles up to 24 rows per CU)
+        monkeypatch.setenv("UAVAGENT_HEAD_RB", tile)
     g = torch.Generator(device="cuda").manual_seed(n_rows)
     rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
     H, NA = 200, 625
@@ -574,7 +577,7 @@ def test_graph_captured_rollout_equals_the_eager_rollout(first, second):
     r1, r2 = _twin_runners(torch, 512, 6, max_step=15, first=dict(first), second=dict(second))
     assert (r1._halves is not None) == (first["pipeline_halves"] == "force") and (r2._halves is not None) == (second["pipeline_halves"] == "force")
     if r1._halves is not None:
-        assert r1._halves == ((0, 288), (288, 512))                # cut on a multiple of lcm(3 envs per wavefront, 32-row head tiles)
+        assert r1._halves == ((0, 256), (256, 512))                # cut on a multiple of the head's 16-row tiles (inside an env wavefront: 256 = 85 x 3 + 1)
     for it in range(4):                                            # crosses done + masked reset (MAXSTEP 15 inside rollout 3)
         b1, b2 = r1.collect(), r2.collect()
         for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):

@@ -361,18 +361,18 @@ def test_graph_replay_of_steps_is_bit_identical_to_eager():
         assert np.array_equal(env.get_state(), ref.get_state())
 
 
-@pytest.mark.parametrize("shape", [(100, 4, 20, 33), (50, 4, 40, 7), (10, 16, 200, 4), (20, 8, 20, 9)], ids=lambda s: "%denv_%dx%d_cut%d" % s)
+@pytest.mark.parametrize("shape", [(100, 4, 20, 33), (100, 4, 20, 32), (100, 4, 20, 49), (50, 4, 40, 7), (10, 16, 200, 4), (20, 8, 20, 9), (4097, 4, 20, 2048)],
+                         ids=lambda s: "%denv_%dx%d_cut%d" % s)
 def test_step_range_over_two_ranges_equals_step(shape):
     """uavenv_step_range on [0, cut) and [cut, N) -- on two streams, concurrently -- leaves the outputs and the state one uavenv_step of
-    the whole batch leaves (what the A2C rollout's two half-batches rely on); ranges that split a wavefront's envs are refused."""
+    the whole batch leaves (what the A2C rollout's two half-batches rely on), also when the cut falls inside a wavefront's envs (that
+    wavefront then runs in both launches, each with its own envs live)."""
     torch = _torch()
     from drl_uav_cellularnet_amd import _capi
 
     n, n_bs, n_ue, cut = shape
     env = _env(n, n_bs, n_ue)
     ref = env.clone()
-    epw = env.envs_per_wavefront
-    assert cut % epw == 0
     act = _actions(torch, env, 5, 11)
     s1 = torch.cuda.Stream()
     for t in range(5):
@@ -385,10 +385,9 @@ def test_step_range_over_two_ranges_equals_step(shape):
         for k in ref.out:
             assert torch.equal(env.out[k], ref.out[k]), "%s differs at step %d" % (k, t)
     assert np.array_equal(env.get_state(), ref.get_state())
-    if epw > 1:
-        with pytest.raises(_capi.UavEnvError, match="range"):
-            env.step_range(act[0], 1, epw)                        # starts inside a wavefront
-        with pytest.raises(_capi.UavEnvError, match="range"):
-            env.step_range(act[0], 0, epw + 1)                    # ends inside one
     with pytest.raises(_capi.UavEnvError, match="range"):
-        env.step_range(act[0], 0, n + epw)
+        env.step_range(act[0], 0, n + 1)
+    with pytest.raises(_capi.UavEnvError, match="range"):
+        env.step_range(act[0], n, 1)
+    with pytest.raises(_capi.UavEnvError, match="range"):
+        env.step_range(act[0], 0, 0)

@@ -6,15 +6,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from drl_uav_cellularnet_amd import BatchedMobiEnv
 from drl_uav_cellularnet_amd.agent import A2CRunner
-variants = {"default (pipelined halves)": {}, "unsplit (round 3)": {"pipeline_halves": False}, "separate_obs_indices": {"fused_obs": False},
+variants = {"default (pipelined halves, heads alternate)": {"pipeline_halves": True}, "unsplit (round 3)": {"pipeline_halves": False}, "separate_obs_indices": {"fused_obs": False},
             "three_launches": {"fused_head": False}}
 if len(sys.argv) > 1:
     variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
-variants["pipelined, free-running with a one-gather stagger"] = {"_mode": "stagger"}
+for parts in (2, 3, 4):
+    for mode in ("alternate", "free", "stagger"):
+        if (parts, mode) != (2, "alternate"):
+            variants["pipelined %d parts, %s" % (parts, mode)] = {"_mode": mode, "_parts": parts, "pipeline_halves": True}
+if len(sys.argv) > 1:
+    variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
 runners = {}
 for k, kw in variants.items():
     kw = dict(kw)
     os.environ["UAVAGENT_PIPE_MODE"] = kw.pop("_mode", "alternate")
+    os.environ["UAVAGENT_PIPE_PARTS"] = str(kw.pop("_parts", 2))
     env = BatchedMobiEnv(8192, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
     runners[k] = A2CRunner(env, rollout=50, **kw)
     runners[k].collect(); runners[k].collect()

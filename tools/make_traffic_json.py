@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/traffic_current.json from the rocprofv3 output directories of ONE gpurun call of tools/r03_pmc.sh.
+"""profiles/traffic_current.json from the rocprofv3 output directories of ONE gpurun call of tools/r04_pmc.sh.
 
-    python tools/make_traffic_json.py gpurun_out/r03e profiles/r03e   (second argument: prefix the cited evidence files get in profiles/)
+    python tools/make_traffic_json.py gpurun_out/r04e profiles/r04e   (second argument: prefix the cited evidence files get in profiles/)
 
 Per workload (tag of r03_pmc.sh) the PMC passes are reduced to figures PER CALL of the step entry point: a uavenv_step_many call is one
 kernel dispatch, or D dispatches of the same kernel under the rotation schedule (csrc/uavenv_capi.hip: rotation_plan), so counters and
@@ -53,12 +53,13 @@ def stats(d):
 
 def main():
     root, cite = sys.argv[1], sys.argv[2]
-    # tag -> (envs, n_bs, n_ue, MANY kernel?, steps per call, steps run under the trace pass, steps run under each PMC pass); the bench
-    # runs warm-up + timed steps through the entry point (r03_pmc.sh: --warmup 100 + --steps ...)
-    work = {"many": (4096, 4, 20, True, 100, 2100, 500), "seq": (4096, 4, 20, False, 1, None, None),
-            "many65536": (65536, 4, 20, True, 100, 700, 300), "c5": (8192, 16, 200, False, 1, None, None)}
+    # the manifest tools/r04_pmc.sh wrote in the same gpurun call: per tag the workload, the dispatch form and the step counts it ran
+    # (the bench runs warm-up + timed steps through the entry point)
+    runs = json.load(open(os.path.join(root, "runs.json")))["runs"]
     entries = []
-    for tag, (envs, n_bs, n_ue, many, spc, trace_steps, pmc_steps) in work.items():
+    for rn in runs:
+        tag, envs, n_bs, n_ue, many, spc = rn["tag"], rn["envs"], rn["n_bs"], rn["n_ue"], bool(rn["many"]), rn["steps_per_call"]
+        trace_steps, pmc_steps = rn["warmup"] + rn["trace_steps"], rn["warmup"] + rn["pmc_steps"]
         c = {}
         for p in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
             for k, v in counters(os.path.join(root, "pmc_%s_%s" % (tag, p))).items():
@@ -67,27 +68,32 @@ def main():
         for k in sorted(c):
             if "STEP" not in k or ("MANY=1" in k) != many and "packed" in k:
                 continue
-            if tag == "many" and "MANY=0" in k:
-                continue                              # (the scratch-env pre-warm's single steps: described by the seq pass)
+            if many and "MANY=0" in k:
+                continue                              # (the scratch-env pre-warm's single steps: described by the seq passes)
             cc = c[k]
             if many:
                 calls_pmc, calls_tr = pmc_steps // spc, trace_steps // spc
             else:
                 calls_pmc, calls_tr = cc["FETCH_SIZE"][0], st[k][0]        # one dispatch per call
-            e = {"envs": envs, "n_bs": n_bs, "n_ue": n_ue, "kernel": k, "steps_per_launch": spc,
-                 "dispatches_per_call": round(cc["FETCH_SIZE"][0] / float(calls_pmc), 3),
+            dpc = cc["FETCH_SIZE"][0] / float(calls_pmc)
+            e = {"envs": envs, "n_bs": n_bs, "n_ue": n_ue, "kernel": k, "steps_per_launch": spc, "schedule": rn["schedule"],
+                 "dispatches_per_call": round(dpc, 3),
                  "fetch_size_bytes_raw": int(round(cc["FETCH_SIZE"][1] * 1024 / calls_pmc)),
                  "write_size_bytes_raw": int(round(cc["WRITE_SIZE"][1] * 1024 / calls_pmc)),
-                 "valu_insts_per_launch": round(cc["SQ_INSTS_VALU"][1] / (cc["SQ_INSTS_VALU"][0] / (cc["FETCH_SIZE"][0] / float(calls_pmc))), 1),
-                 "waves_per_launch": round(cc["SQ_WAVES"][1] / (cc["SQ_WAVES"][0] / (cc["FETCH_SIZE"][0] / float(calls_pmc))), 1),
+                 "valu_insts_per_launch": round(cc["SQ_INSTS_VALU"][1] / (cc["SQ_INSTS_VALU"][0] / dpc), 1),
+                 "waves_per_launch": round(cc["SQ_WAVES"][1] / (cc["SQ_WAVES"][0] / dpc), 1),
                  "sq_wait_any_over_wave_cycles": round(cc["SQ_WAIT_ANY"][1] / cc["SQ_WAVE_CYCLES"][1], 4),
                  "rocprof_avg_kernel_ns": round(st[k][1] / calls_tr, 1),
                  "source": "%s_pmc_and_trace_digest.txt (PMC: %d dispatches), %s_%s_kernel_stats.csv (%d dispatches)" % (
                      cite, cc["FETCH_SIZE"][0], cite, tag, st[k][0])}
+            expect = {"plain": 1.0, "one_launch_rotation": 1.0}.get(rn["schedule"])
+            if expect is not None and abs(dpc - expect) > 0.05:
+                e["WARNING"] = "expected %.0f dispatch(es) per call for schedule %s" % (expect, rn["schedule"])
             entries.append(e)
-    doc = {"note": "Per-CALL rocprofv3 figures of the step kernels (one uavenv_step / uavenv_step_many call = 1 dispatch, or D dispatches under the "
-                   "rotation schedule: summed), three separate PMC passes each (FETCH_SIZE / WRITE_SIZE / SQ counters) plus a kernel trace, all "
-                   "from one gpurun call (tools/r03_pmc.sh).  fetch/write are RAW counter values (KB x 1024).  Every state load of these kernels "
+    doc = {"note": "Per-CALL rocprofv3 figures of the step kernels, one entry per DISPATCH FORM (kernel, batch, steps per call, schedule: plain launch / "
+                   "one-launch rotation): bench.py uses an entry only for a run of exactly that form and prints traffic: null otherwise.  Three "
+                   "separate PMC passes each (FETCH_SIZE / WRITE_SIZE / SQ counters) plus a kernel trace, all from one gpurun call (tools/r04_pmc.sh; its "
+                   "runs.json manifest carries the step counts).  fetch/write are RAW counter values (KB x 1024).  Every state load of these kernels "
                    "is a 16 B/lane dwordx4 record load, the case where gfx950 reports exactly half (MI355X_MICROARCH.md, HBM): bench.py doubles "
                    "FETCH_SIZE.  Generated by tools/make_traffic_json.py; kernel = the library's launch-census name.",
            "entries": entries}
