@@ -575,6 +575,9 @@ def a2c_roofline(runner, envs, T):
 
     N, H, NA, K = envs, 200, runner.net.n_action, runner.env.nBS + runner.env.nUE
     M = N * T
+    parts = getattr(runner, "_halves", None) or ((0, N),)      # pipelined halves: the rollout's kernels run per half, on two streams
+    n_parts = len(parts)
+    Nr = (parts[0][1] - parts[0][0])                           # rows per rollout-kernel launch (the parts are equal at 8192 envs)
     was = runner.collect_launch
     runner.collect_launch = "eager"
     torch.cuda.synchronize()
@@ -595,7 +598,7 @@ def a2c_roofline(runner, envs, T):
     env_us = e0.elapsed_time(e1) * 1e3 / T
 
     def entry(keys, work, unit, roof, roof_src, what, calls_per_rollout):
-        ms = [m for k in keys for m in times.get(k, [])]
+        ms = [m for k in sorted(set(keys)) for m in times.get(k, [])]
         if not ms:
             return None
         avg_us = sum(ms) / len(ms) * 1e3
@@ -607,11 +610,13 @@ def a2c_roofline(runner, envs, T):
     mfma = ("dense float32 MFMA peak (MI355X_MICROARCH.md)", MFMA_F32_PEAK_TFLOPS)
     out = {}
     rows = [
-        ("actor_head", ["uavagent_actor_head_f32[rows=%d]" % N], 2.0 * N * (H * H + H * NA), "TFLOP/s", mfma[1], mfma[0],
-         "rollout step: layer 2 + policy head + action draw, one kernel (main.py:147-150,165-169)", T),
-        ("first_layer_gather", ["uavagent_first_layer_from_obs_f32[rows=%d]" % N], float(N) * K * 2 * H * 4, "TB/s", GATHER_CACHE_TBPS,
+        ("actor_head", ["uavagent_actor_head_f32[rows=%d]" % (hi - lo) for lo, hi in parts], 2.0 * Nr * (H * H + H * NA), "TFLOP/s", mfma[1], mfma[0],
+         "rollout step: layer 2 + policy head + action draw, one kernel (main.py:147-150,165-169)%s" % (
+             "; per HALF of the batch, timed beside the other half's gather / env step" if n_parts > 1 else ""), T * n_parts),
+        ("first_layer_gather", ["uavagent_first_layer_from_obs_f32[rows=%d]" % (hi - lo) for lo, hi in parts], float(Nr) * K * 2 * H * 4, "TB/s", GATHER_CACHE_TBPS,
          "gather of 1 600-byte row pairs out of two 40 MB tables: MI355X_MICROARCH.md 'Indexed rows', 38 MB table 8.6 TB/s chip-wide",
-         "rollout step: first layer of both trunks from the compact observation (sum of B + U table rows per env)", T - 1),
+         "rollout step: first layer of both trunks from the compact observation (sum of B + U table rows per env)%s" % (
+             "; per HALF of the batch, timed beside the other half's actor head" if n_parts > 1 else ""), (T - 1) * n_parts),
         ("table_gradient", ["uavagent_rows_grad_sums_f32[M=%d,K=%d]" % (M, K)], float(M) * K * 2 * H * 4, "TB/s", GATHER_LARGE_TBPS,
          "gather of one 1 600-byte g row per (sample, index) pair from a 655 MB array: MI355X_MICROARCH.md 'Indexed rows', 151 MB table "
          "7.4-7.9 TB/s chip-wide", "update: x^T g for the 0/1 first-layer input (both tables)", 1),
@@ -637,7 +642,9 @@ def a2c_roofline(runner, envs, T):
                        "frac": b_step * N / (env_us * 1e-6) / 1e12 / (HBM_PEAK_GBPS / 1e3), "roof_source": "HBM peak (nominal, as the headline's roofline.frac)",
                        "launches_timed": T}
     covered = sum(v["ms_per_rollout"] for v in out.values())
-    return {"kernels": out, "ms_per_rollout_covered": covered,
+    return {"kernels": out, "ms_per_rollout_covered": covered, "rollout_parts_on_streams": n_parts,
+            "ms_per_rollout_covered_note": "sum of avg_us x calls; with the rollout pipelined over two streams the halves' kernels overlap, so the "
+                                           "sum exceeds the wall time of a rollout + update",
             "method": "HIP events around every launch of one extra EAGER rollout + update of this run (after the timed region); back-to-back launches "
                       "on one stream, so a pair brackets its kernel plus ~2 us of launch gap; PMC passes of the same kernels: profiles/ (DESIGN 10c/10d)",
             "all_launches_ms": {k: round(sum(v), 4) for k, v in sorted(times.items())}}

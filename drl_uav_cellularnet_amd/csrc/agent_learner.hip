@@ -208,6 +208,115 @@ __global__ __launch_bounds__(256) void a2c_loss_grad_kernel(float *__restrict__ 
     if (lane == 0) { loss_partial[wave * 3] = la; loss_partial[wave * 3 + 1] = lc; loss_partial[wave * 3 + 2] = sdv; }
 }
 
+// The same pass for rows that start 16-byte aligned (ld a multiple of 4: the learner's logits live in rows of 640 floats with a zero tail):
+// a lane moves whole float4s (float4 index l, l + 64, ...: a wave instruction touches 1 KB of one row) and the per-element
+// transcendentals are the hardware's (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp) instead of the library's correctly-handled-everywhere
+// expf / logf / IEEE division: at 625 columns the first form spends ~50 VALU instructions per element -- 0.33 ms of pure issue for the
+// update's 2.56e8 elements -- and ran at 3.3-3.9 TB/s; this one is bound by its 2 x 1.05 GB of traffic.  Operand ranges make the fast
+// forms safe: x - max <= 0 (no overflow; underflow to 0 is the exact limit), p + 1e-5 in [1e-5, 1.00001] (normal, no special cases).
+// Padding elements of the last float4 (columns >= A) are read (zero tail) but excluded from every sum and written back as zeros.
+template <int PERV>
+__global__ __launch_bounds__(256) void a2c_loss_grad_vec_kernel(float *__restrict__ logits, const float *__restrict__ v,
+                                                                const float *__restrict__ target, const long long *__restrict__ act,
+                                                                long long M, int A, long long ld, float beta, float inv_m, float *__restrict__ dv,
+                                                                float *__restrict__ col_partial, double *__restrict__ loss_partial) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+    const int nv = (A + 3) >> 2;                         // float4s of a row that hold at least one real column
+    float4 csum[PERV];
+#pragma unroll
+    for (int k = 0; k < PERV; ++k) csum[k] = float4{0.f, 0.f, 0.f, 0.f};
+    double la = 0.0, lc = 0.0, sdv = 0.0;
+    constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    for (long long r = wave; r < M; r += n_waves) {
+        float4 *row = reinterpret_cast<float4 *>(logits + r * ld);
+        float x[PERV][4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < PERV; ++k) {
+            const int i4 = k * 64 + lane;
+            float4 q = float4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            if (i4 < nv) q = row[i4];
+            x[k][0] = q.x; x[k][1] = q.y; x[k][2] = q.z; x[k][3] = q.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i4 * 4 + j >= A) x[k][j] = -3.0e38f;
+                mx = fmaxf(mx, x[k][j]);
+            }
+        }
+        mx = wave_max_f(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PERV; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (k * 64 + lane) * 4 + j < A;
+                x[k][j] = ok ? __builtin_amdgcn_exp2f((x[k][j] - mx) * kLog2e) : 0.f;
+                s += x[k][j];
+            }
+        const float inv = __builtin_amdgcn_rcpf(wave_sum_f(s));
+        const float td = target[r] - v[r];
+        const int a = (int)act[r];
+        float gp[PERV][4];
+        float h = 0.f, lpa = 0.f, pa = 0.f;
+#pragma unroll
+        for (int k = 0; k < PERV; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (k * 64 + lane) * 4 + j;
+                const float p = x[k][j] * inv;
+                x[k][j] = p;
+                const float q = p + 1e-5f;
+                const float lp = __builtin_amdgcn_logf(q) * kLn2;
+                h -= p * lp;                                             // entropy term (:71-72); p == 0 on padding elements
+                gp[k][j] = beta * (lp + p * __builtin_amdgcn_rcpf(q));
+                if (c == a) { lpa = lp; pa = p; }
+            }
+        lpa = wave_sum_f(lpa);
+        pa = wave_sum_f(pa);
+        h = wave_sum_f(h);
+        const float tda = td * __builtin_amdgcn_rcpf(pa + 1e-5f);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < PERV; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (k * 64 + lane) * 4 + j;
+                if (c == a) gp[k][j] -= tda;
+                dot += x[k][j] * gp[k][j];
+            }
+        dot = wave_sum_f(dot);
+#pragma unroll
+        for (int k = 0; k < PERV; ++k) {
+            const int i4 = k * 64 + lane;
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = (i4 * 4 + j < A) ? x[k][j] * (gp[k][j] - dot) * inv_m : 0.f;
+            if (i4 < nv) {
+                row[i4] = float4{g[0], g[1], g[2], g[3]};
+                csum[k].x += g[0]; csum[k].y += g[1]; csum[k].z += g[2]; csum[k].w += g[3];
+            }
+        }
+        if (lane == 0) {
+            const float g = -2.f * td * inv_m;
+            dv[r] = g;
+            sdv += (double)g;
+            la += (double)(-(beta * h + lpa * td));                 // :73-74
+            lc += (double)(td * td);                                // :66
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PERV; ++k) {
+        const int c0 = (k * 64 + lane) * 4;
+        const float cs[4] = {csum[k].x, csum[k].y, csum[k].z, csum[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < A) col_partial[wave * A + c0 + j] = cs[j];
+    }
+    if (lane == 0) { loss_partial[wave * 3] = la; loss_partial[wave * 3 + 1] = lc; loss_partial[wave * 3 + 2] = sdv; }
+}
+
 // out[c] = sum_w partial[w][c] in a FIXED order (deterministic): a block owns 64 columns; its 16 slab-threads per column each add
 // a contiguous slab of the partial rows in ascending order (64 consecutive floats per load instruction: coalesced), then the
 // 16 slab sums are added in slab order.  (The first version, one thread per column over all 4096 partial rows, took 0.99 ms per
@@ -575,6 +684,16 @@ extern "C" int uavagent_a2c_loss_grad(float *logits_inout, int64_t ld_logits, co
     const long long *ac = reinterpret_cast<const long long *>(actions);
 #define UAVAGENT_LOSS(P_) hipLaunchKernelGGL((a2c_loss_grad_kernel<P_>), dim3(kLossBlocks), dim3(256), 0, s, logits_inout, v, v_target, ac, \
                                              (long long)m_rows, (int)n_actions, (long long)ld_logits, beta, inv_m, dv_out, colp, lossp)
+    // rows that start 16-byte aligned (the learner's: ld 640): the float4 form; UAVAGENT_LOSS_SCALAR=1 keeps the first form (A/B runs)
+    const char *force_scalar = getenv("UAVAGENT_LOSS_SCALAR");
+    const bool vec = ((reinterpret_cast<uintptr_t>(logits_inout) & 15) == 0) && ((ld_logits & 3) == 0) && (ld_logits >= ((n_actions + 3) & ~3)) &&
+                     !(force_scalar && force_scalar[0] == '1');
+#define UAVAGENT_LOSSV(P_) hipLaunchKernelGGL((a2c_loss_grad_vec_kernel<P_>), dim3(kLossBlocks), dim3(256), 0, s, logits_inout, v, v_target, ac, \
+                                              (long long)m_rows, (int)n_actions, (long long)ld_logits, beta, inv_m, dv_out, colp, lossp)
+    if (vec) {
+        const int nv = (n_actions + 3) / 4;
+        if (nv <= 64) UAVAGENT_LOSSV(1); else if (nv <= 128) UAVAGENT_LOSSV(2); else if (nv <= 192) UAVAGENT_LOSSV(3); else UAVAGENT_LOSSV(4);
+    } else
     switch (per_lane_cols(n_actions)) {
         case 1: UAVAGENT_LOSS(1); break;
         case 2: UAVAGENT_LOSS(2); break;
@@ -584,6 +703,7 @@ extern "C" int uavagent_a2c_loss_grad(float *logits_inout, int64_t ld_logits, co
         default: UAVAGENT_LOSS(16); break;
     }
 #undef UAVAGENT_LOSS
+#undef UAVAGENT_LOSSV
     if (int rc = launch_ok("a2c_loss_grad")) return rc;
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n_actions + 63) / 64), dim3(1024), 0, s, colp, waves, (int)n_actions, dbias_out);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, s, lossp, waves, 1.0 / (double)m_rows, loss_out);

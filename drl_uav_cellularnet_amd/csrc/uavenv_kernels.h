@@ -1336,9 +1336,11 @@ void env_kernel_multipass(const KParams p) {
             if (!item) {
                 // A ROLLED loop over the HB fading pairs with running reductions instead of a pg[BT] array: the unrolled form
                 // needed 204-206 VGPRs (2 wavefronts per SIMD) and 83-118 SGPR spills at BT = 16.  What SINR needs from the B
-                // powers: the first maximum and the sum of the OTHERS (a displaced maximum joins that sum when it is displaced,
-                // so nothing is ever subtracted), and for the serving UAV its power and the sum of the others in index order.
-                double bp = 0.0, others_b = 0.0, ps = 0.0, others_s = 0.0;
+                // powers: the first maximum and the sum of the OTHERS in the reference's order -- channel.py:259-268 adds the other UAVs'
+                // powers by ascending index -- and for the serving UAV its power and the same sum.  `all` is the plain left-to-right sum
+                // of every power so far; while UAV m is the best one, others_b = (sum of the powers before m) + the powers after m, one
+                // by one; when a later power displaces m, the sum of everything before it IS `all`.  Nothing is ever subtracted.
+                double bp = 0.0, others_b = 0.0, all = 0.0, ps = 0.0, others_s = 0.0;
                 best = 0;
                 U4 qq = {0u, 0u, 0u, 0u};                                       // quad mode: the current four-UAV call
 #pragma unroll 1
@@ -1356,15 +1358,19 @@ void env_kernel_multipass(const KParams p) {
                         fading_pair(H, C, q, f0, f1);
                     }
                     const double g0 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
-                    if (k == 0) { bp = g0; best = 0; }
-                    else if (g0 > bp) { others_b += bp; bp = g0; best = b0; }
-                    else others_b += g0;
+                    if (k == 0) { bp = g0; best = 0; all = g0; }
+                    else {
+                        if (g0 > bp) { others_b = all; bp = g0; best = b0; }
+                        else others_b += g0;
+                        all += g0;
+                    }
                     others_s += (b0 == serving) ? 0.0 : g0;
                     ps = (b0 == serving) ? g0 : ps;
                     if (b1 < B) {
                         const double g1 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b1], bs_row[2 * b1 + 1], f1);
-                        if (g1 > bp) { others_b += bp; bp = g1; best = b1; }
+                        if (g1 > bp) { others_b = all; bp = g1; best = b1; }
                         else others_b += g1;
+                        all += g1;
                         others_s += (b1 == serving) ? 0.0 : g1;
                         ps = (b1 == serving) ? g1 : ps;
                     }
@@ -1390,14 +1396,24 @@ void env_kernel_multipass(const KParams p) {
                 double bp = g0; best = b0;
                 if (b1 < B && g1 > g0) { bp = g1; best = b1; }             // first maximum inside the pair, then across the group
                 group_argmax(bp, best, IT);
-                // interference = the OTHER UAVs (never total - self); the group sum adds them in butterfly order
-                const double ib = group_sum(((b0 != best) ? g0 : 0.0) + ((b1 != best && b1 < B) ? g1 : 0.0), IT);
-                bestS = H.db_per_ln * lm_logc(lm_div(bp, H.noise + ib), C);
-                if (!is_reset(MODE)) {
-                    const double is = group_sum(((b0 != serving) ? g0 : 0.0) + ((b1 != serving && b1 < B) ? g1 : 0.0), IT);
-                    const double ps = group_sum(((b0 == serving) ? g0 : 0.0) + ((b1 == serving && b1 < B) ? g1 : 0.0), IT);
-                    cur = H.db_per_ln * lm_logc(lm_div(ps, H.noise + is), C);
+                // interference = the OTHER UAVs, never total - self, added by ascending UAV index like channel.py:259-268: every lane of the
+                // group walks the group's IT pairs in order (the sums of the best and of the serving UAV share the shuffles)
+                double ib = 0.0, is = 0.0, ps = 0.0;
+                const int g_lane0 = lane - hb;
+                for (int k = 0; k < IT; ++k) {
+                    const double a0 = __shfl(g0, g_lane0 + k, 64), a1 = __shfl(g1, g_lane0 + k, 64);
+                    const int j0 = 2 * k, j1 = 2 * k + 1;
+                    ib += (j0 == best) ? 0.0 : a0;
+                    is += (j0 == serving) ? 0.0 : a0;
+                    ps = (j0 == serving) ? a0 : ps;
+                    if (j1 < B) {
+                        ib += (j1 == best) ? 0.0 : a1;
+                        is += (j1 == serving) ? 0.0 : a1;
+                        ps = (j1 == serving) ? a1 : ps;
+                    }
                 }
+                bestS = H.db_per_ln * lm_logc(lm_div(bp, H.noise + ib), C);
+                if (!is_reset(MODE)) cur = H.db_per_ln * lm_logc(lm_div(ps, H.noise + is), C);
             }
 
             // ---- handover, outage, stores ------------------------------------------------------------------------

@@ -73,7 +73,10 @@ int uavagent_sample_actions(const float *logits, int64_t ld_logits, const float 
  * v_target f32 [m_rows], actions int64 [m_rows].  OUT: logits_inout overwritten with d(a_loss)/d(logits); dv_out [m_rows] =
  * d(c_loss)/dv; dbias_out [n_actions] = column sums of the logits gradient; loss_out double[3] = {a_loss, c_loss, sum(dv)}.
  *   td = v_target - v;  c_loss = mean(td^2);  a_loss = mean(-(beta * H + log(p[a] + 1e-5) * td)),  H = -sum p log(p + 1e-5),
- *   td enters a_loss as a constant (tf.stop_gradient, main.py:70). */
+ *   td enters a_loss as a constant (tf.stop_gradient, main.py:70).
+ * Rows that start 16-byte aligned with ld_logits a multiple of 4 (the learner's: 625 logits in rows of 640) take a float4 kernel that uses
+ * the hardware's exp2 / log2 / reciprocal (about 1 ulp each); it also writes zeros to the columns [n_actions, n_actions rounded up to 4) of
+ * every row (the learner keeps that tail zero anyway).  Other layouts take the dword kernel with the library's expf / logf. */
 size_t uavagent_loss_grad_workspace_bytes(int32_t n_actions);
 int uavagent_a2c_loss_grad(float *logits_inout, int64_t ld_logits, const float *v, const float *v_target, const int64_t *actions,
                            int64_t m_rows, int32_t n_actions, float beta, float *dv_out, float *dbias_out, double *loss_out,

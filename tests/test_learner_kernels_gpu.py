@@ -144,13 +144,17 @@ def test_sample_actions_kernel_is_the_inverse_cdf_draw():
         assert int((got != ref).sum()) <= 1
 
 
-@pytest.mark.parametrize("shape", [(4096, 625), (1000, 5), (300, 100)])
+@pytest.mark.parametrize("shape", [(4096, 625, 640), (4096, 625, 625), (1000, 5, 5), (300, 100, 100), (513, 1000, 1000), (700, 256, 260), (257, 513, 516)],
+                         ids=lambda s: "M%d_A%d_ld%d" % s)
 def test_loss_grad_kernel_matches_autograd(shape):
+    """uavagent_a2c_loss_grad against autograd of agent.a2c_losses (main.py:64-74).  Rows of ld floats: a multiple of 4 takes the float4
+    kernel with the hardware's exp2 / log2 / rcp (the learner's own logits: 625 columns in rows of 640 with a zero tail, which must stay
+    zero), anything else the dword kernel with the library's expf / logf."""
     torch = _torch()
     from drl_uav_cellularnet_amd import _agent_capi as A
     from drl_uav_cellularnet_amd.agent import a2c_losses
 
-    M, NA = shape
+    M, NA, LD = shape
     g = torch.Generator(device="cuda").manual_seed(11)
     logits = (torch.randn(M, NA, device="cuda", generator=g) * 2).requires_grad_()
     v = torch.randn(M, 1, device="cuda", generator=g).requires_grad_()
@@ -158,7 +162,9 @@ def test_loss_grad_kernel_matches_autograd(shape):
     act = torch.randint(0, NA, (M,), device="cuda", generator=g)
     a_loss, c_loss = a2c_losses(torch.softmax(logits, dim=1), v, act, target, beta=0.001)
     (a_loss + c_loss).backward()
-    work = logits.detach().clone()
+    pad = torch.zeros((M, LD), device="cuda")
+    pad[:, :NA] = logits.detach()
+    work = pad[:, :NA]                                  # rows contiguous, row stride LD
     dv = torch.empty(M, device="cuda")
     db = torch.empty(NA, device="cuda")
     loss = torch.zeros(3, dtype=torch.float64, device="cuda")
@@ -170,6 +176,7 @@ def test_loss_grad_kernel_matches_autograd(shape):
     torch.testing.assert_close(db, logits.grad.sum(dim=0), rtol=1e-4, atol=1e-5 * float(logits.grad.sum(dim=0).abs().max()) + 1e-9)
     np.testing.assert_allclose(loss.cpu().numpy()[:2], [float(a_loss), float(c_loss)], rtol=1e-5)
     np.testing.assert_allclose(float(loss[2]), float(v.grad.sum()), rtol=1e-4, atol=1e-7)
+    assert float(pad[:, NA:].abs().max()) == 0.0 if LD > NA else True          # the zero tail the update's GEMMs read stays zero
 
 
 def test_relu6_bwd_and_value_head_kernels():
