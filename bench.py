@@ -49,7 +49,7 @@ PREWARM_STEPS = 400           # untimed steps on a scratch env right before the 
 CPU_THREAD_CAP = 16           # cpu_baseline threads: the CPU share of a one-GPU job on this pool (stated in the line)
 
 
-SCHEDULE_NAMES = {0: "plain", 1: "one_launch_rotation", 2: "several_launch_rotation"}   # uavenv_debug_rotation_info: launches per call
+SCHEDULE_NAMES = {0: "plain", 1: "one_launch_rotation"}   # uavenv_debug_rotation_info: launches per call
 
 
 def algorithmic_bytes_per_env_step(U, B, Gr):
@@ -485,7 +485,7 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
 
         nl, sl = C.c_int(0), C.c_longlong(0)
         env._lib.uavenv_debug_rotation_info(env._h, min(ck, K), C.byref(nl), C.byref(sl))
-        sched = {"form": SCHEDULE_NAMES.get(min(nl.value, 2), "?"), "dispatches_per_call": max(1, nl.value), "wavefronts_per_dispatch": sl.value or None}
+        sched = {"form": SCHEDULE_NAMES.get(nl.value, "?"), "dispatches_per_call": max(1, nl.value), "wavefronts_per_dispatch": sl.value or None}
     return elapsed, gpu_ms, {"kernels": kernels, "per_rank_elapsed_s": [p[0] for p in per_rank],
                              "per_rank_gpu_ms": [p[1] for p in per_rank], "schedule": sched, "device_error": env.device_error()}
 

@@ -229,16 +229,33 @@ __global__ __launch_bounds__(256) void a2c_loss_grad_vec_kernel(float *__restric
     for (int k = 0; k < PERV; ++k) csum[k] = float4{0.f, 0.f, 0.f, 0.f};
     double la = 0.0, lc = 0.0, sdv = 0.0;
     constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    // the NEXT row of this wavefront is loaded while the current one is computed and stored (two rows in flight per wavefront)
+    float4 nxt[PERV];
+    auto load_row = [&](long long r) {
+        const float4 *row = reinterpret_cast<const float4 *>(logits + r * ld);
+#pragma unroll
+        for (int k = 0; k < PERV; ++k) {
+            const int i4 = k * 64 + lane;
+            nxt[k] = float4{0.f, 0.f, 0.f, 0.f};
+            if (i4 < nv) nxt[k] = row[i4];
+        }
+    };
+    if (wave < M) load_row(wave);
     for (long long r = wave; r < M; r += n_waves) {
         float4 *row = reinterpret_cast<float4 *>(logits + r * ld);
         float x[PERV][4];
         float mx = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < PERV; ++k) {
-            const int i4 = k * 64 + lane;
-            float4 q = float4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-            if (i4 < nv) q = row[i4];
+            const float4 q = nxt[k];
             x[k][0] = q.x; x[k][1] = q.y; x[k][2] = q.z; x[k][3] = q.w;
+        }
+        const float td = target[r] - v[r];
+        const int a = (int)act[r];
+        if (r + n_waves < M) load_row(r + n_waves);
+#pragma unroll
+        for (int k = 0; k < PERV; ++k) {
+            const int i4 = k * 64 + lane;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (i4 * 4 + j >= A) x[k][j] = -3.0e38f;
@@ -256,8 +273,6 @@ __global__ __launch_bounds__(256) void a2c_loss_grad_vec_kernel(float *__restric
                 s += x[k][j];
             }
         const float inv = __builtin_amdgcn_rcpf(wave_sum_f(s));
-        const float td = target[r] - v[r];
-        const int a = (int)act[r];
         float gp[PERV][4];
         float h = 0.f, lpa = 0.f, pa = 0.f;
 #pragma unroll

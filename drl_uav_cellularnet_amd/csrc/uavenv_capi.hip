@@ -38,8 +38,7 @@ struct uavenv {
     struct RotPlan { int n_steps; int n_launches; long long slots; int4 *dev; };   // rotation schedules built so far (one per n_steps;
                                                                                   // n_launches 0 = none applies: plain launch)
     std::vector<RotPlan> *rot_plans;
-    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 the one-launch schedule whenever one exists
-                        // (tests), 2 the several-launch schedule of round 3 whenever one exists (A/B runs)
+    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 whenever a schedule exists (tests)
     long long rot_slots;  // UAVENV_ROTATE_SLOTS (tests: pretend the device has this many SIMDs), else n_simd
     uint32_t *sched_flag_dev;   // [env-wavefronts] hand-off words of the one-launch schedule (zero between calls)
     uint32_t *err_host, *err_dev;   // sticky device-side error word: host-mapped memory, so that every entry point can test it without a HIP call
@@ -192,7 +191,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     h->force_pin = -1;
     if (const char *f = std::getenv("UAVENV_FORCE_PIN")) h->force_pin = (f[0] == '1') ? 1 : 0;
     h->rotate = -1;
-    if (const char *f = std::getenv("UAVENV_ROTATE")) h->rotate = (f[0] == '1') ? 1 : (f[0] == '2') ? 2 : 0;
+    if (const char *f = std::getenv("UAVENV_ROTATE")) h->rotate = (f[0] == '1') ? 1 : 0;
     h->rot_plans = new (std::nothrow) std::vector<uavenv::RotPlan>();
     h->spin_us = 2000000u;
     if (const char *f = std::getenv("UAVENV_HANDOFF_SPIN_US")) { const long long v = std::atoll(f); if (v > 0 && v < 60000000ll) h->spin_us = (uint32_t)v; }
@@ -584,14 +583,13 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
 // (BASELINE's 4096 envs x 20 UEs: 1366 wavefronts on 1024 SIMDs).  The W x T wavefront-steps fit S slots in M = ceil(W T / S)
 // step-times (McNaughton's wrap-around rule: fill slot after slot; a job that does not fit is split, its LAST steps at the end of this
 // slot, its FIRST steps at the start of the next).  M < 2 T, so a slot holds at most three pieces: [first steps of a split job]
-// [one whole job] [last steps of another split job].
-//   form 1 (round 4, the default): ONE launch of S persistent wavefronts.  The wavefront that ran a job's first steps stores the
-//     state, releases and sets the job's flag; the wavefront that runs its last steps polls the flag (bounded), acquires and loads
-//     (uavenv_kernels.h: sched_hand_off_*).  The publishing piece is the FIRST piece of its slot and waits for nothing, and the
-//     waiting piece starts M - T step-times after the publishing one ended, so in practice nobody waits.
-//   form 2 (round 3, kept for A/B runs, UAVENV_ROTATE=2): the slots' timelines cut at D = ceil(M / (M - T)) common boundaries give D
-//     launches; a split job's two parts are at least M - T step-times apart, hence in different launches, and stream order is the
-//     synchronisation.  Each launch costs the ~8 us of load / store / launch phases a launch has: it paid from 48 steps on only.
+// [one whole job] [last steps of another split job].  ONE launch of S persistent wavefronts runs it: the wavefront that ran a job's
+// first steps stores the state, releases and sets the job's flag; the wavefront that runs its last steps polls the flag (bounded),
+// acquires and loads (uavenv_kernels.h: sched_hand_off_*).  The publishing piece is the FIRST piece of its slot and waits for nothing,
+// and the waiting piece starts M - T step-times after the publishing one ended, so in practice nobody waits.
+// (Round 3 cut the slots' timelines at D = ceil(M / (M - T)) common boundaries into D launches ordered by the stream; each launch cost
+// the ~8 us of load / store / launch phases a launch has, it paid from 48 steps on only and lost to this form at every size measured:
+// profiles/r04a_many_ab_three_launch_forms.json.  Removed.)
 // Returns the index of the cached / newly built plan in h->rot_plans, or -1 when no schedule applies (then the plain launch runs).
 static long long rot_padded_slots(long long S) { return (S + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock; }
 static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
@@ -613,105 +611,73 @@ static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
     };
     const long long M = (W * T + S - 1) / S;                       // makespan in step-times
     if (M - T < 1 || M >= 2 * (long long)T) return remember(0, nullptr);
-    const bool one_launch = h->rotate != 2;
     // Automatic use only where it pays.  One wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take
     // (2.77 vs 4.31 us at 4096 envs), and the pinned kernel keeps at most two wavefronts resident per SIMD: k <= 2, W / S <= 1.45.
-    // A hand-off costs its two wavefronts a state store + release and a poll + acquire + state load (~10 us together, measured),
-    // against ~0.6 us gained per step: from 16 steps per call on.
+    // A hand-off costs its two wavefronts a state store + release and a poll + acquire + state load (a 20-step call: 97.7 us plain,
+    // 91.0 us with the schedule, 75 us of it the steps), against ~0.6 us gained per step: from 16 steps per call on.
     if (h->rotate == -1 && (k_res > 2 || 100 * W > 145 * S || T < 16)) return remember(0, nullptr);
-    long long D = 1;
-    if (!one_launch) {
-        D = (M + (M - T) - 1) / (M - T);                           // launches: windows no longer than M - T
-        if (D > 64) return remember(0, nullptr);
-    }
-    std::vector<long long> bound((size_t)D + 1);
-    for (long long k = 0; k <= D; ++k) bound[(size_t)k] = k * M / D;
     struct Piece { int ew, t0, nt; long long time; };
-    std::vector<std::vector<Piece>> cell((size_t)(D * S));        // [launch][slot] -> pieces
-    std::vector<int> last_launch((size_t)W, -1), next_step((size_t)W, 0);
+    std::vector<std::vector<Piece>> cell((size_t)S);              // [slot] -> pieces
     bool ok = true;
-    auto place = [&](long long slot, long long time, int ew, int step, int len) {   // a run of `len` steps of job ew at `time` on `slot`
-        while (len > 0 && ok) {
-            long long k = 0;
-            while (bound[(size_t)k + 1] <= time) ++k;                               // window of `time`
-            const int n = (int)std::min<long long>(len, bound[(size_t)k + 1] - time);
-            cell[(size_t)(k * S + slot)].push_back(Piece{ew, step, n, time});
-            time += n; step += n; len -= n;
-        }
-    };
     {   // McNaughton fill.  The FIRST steps of a split job go to the next slot's start.
         long long slot = 0, t = 0;
         for (long long j = 0; j < W && ok; ++j) {
             if (slot >= S) { ok = false; break; }
             if (t + T <= M) {
-                place(slot, t, (int)j, 0, T);
+                cell[(size_t)slot].push_back(Piece{(int)j, 0, T, t});
                 t += T;
                 if (t == M) { ++slot; t = 0; }
             } else {
                 const int a = (int)(M - t);                                         // steps that still fit here: the job's LAST a steps
                 if (slot + 1 >= S) { ok = false; break; }
-                place(slot + 1, 0, (int)j, 0, T - a);
-                place(slot, t, (int)j, T - a, a);
+                cell[(size_t)slot + 1].push_back(Piece{(int)j, 0, T - a, 0});
+                cell[(size_t)slot].push_back(Piece{(int)j, T - a, a, t});
                 ++slot; t = T - a;
             }
         }
     }
     for (auto &c : cell) std::sort(c.begin(), c.end(), [](const Piece &x, const Piece &y) { return x.time < y.time; });
-    // Verify what the argument above promises.  Both forms: every job's steps 0..T-1 exactly once, at most kSchedPieces pieces per
-    // (launch, slot).  Form 2: a job's pieces in launches that strictly increase with the step index.  Form 1: a job is one whole piece,
-    // or two pieces on different slots of which the first one (the one that publishes) LEADS its slot: it can never wait, so every
-    // wait ends -- no deadlock whatever the order in which the hardware starts the wavefronts.
+    // Verify what the argument above promises: every job's steps 0..T-1 exactly once, at most kSchedPieces pieces per slot; a job is one
+    // whole piece, or two pieces on different slots of which the first one (the one that publishes) LEADS its slot: it can never wait,
+    // so every wait ends -- no deadlock whatever the order in which the hardware starts the wavefronts.
     struct Seen { int n, slot0, q0, len0, slot1, t1, len1; };
     std::vector<Seen> seen((size_t)W, Seen{0, -1, -1, 0, -1, 0, 0});
-    for (long long k = 0; k < D && ok; ++k)
-        for (long long sl = 0; sl < S && ok; ++sl) {
-            const auto &c = cell[(size_t)(k * S + sl)];
-            if (c.size() > (size_t)kSchedPieces) ok = false;
-            for (size_t q = 0; q < c.size() && ok; ++q) {
-                const Piece &pc = c[q];
-                if (one_launch) {
-                    Seen &z = seen[(size_t)pc.ew];
-                    if (pc.t0 == 0) { z.slot0 = (int)sl; z.q0 = (int)q; z.len0 = pc.nt; }
-                    else { z.slot1 = (int)sl; z.t1 = pc.t0; z.len1 = pc.nt; }
-                    z.n += 1;
-                    next_step[(size_t)pc.ew] += pc.nt;
-                } else {
-                    if (pc.t0 != next_step[(size_t)pc.ew] || (int)k <= last_launch[(size_t)pc.ew]) { ok = false; break; }
-                    next_step[(size_t)pc.ew] = pc.t0 + pc.nt;
-                    last_launch[(size_t)pc.ew] = (int)k;
-                }
-            }
+    for (long long sl = 0; sl < S && ok; ++sl) {
+        const auto &c = cell[(size_t)sl];
+        if (c.size() > (size_t)kSchedPieces) ok = false;
+        for (size_t q = 0; q < c.size() && ok; ++q) {
+            const Piece &pc = c[q];
+            Seen &z = seen[(size_t)pc.ew];
+            if (pc.t0 == 0) { z.slot0 = (int)sl; z.q0 = (int)q; z.len0 = pc.nt; }
+            else { z.slot1 = (int)sl; z.t1 = pc.t0; z.len1 = pc.nt; }
+            z.n += 1;
         }
-    if (one_launch)
-        for (long long j = 0; j < W && ok; ++j) {
-            const Seen &z = seen[(size_t)j];
-            if (z.n == 1) ok = z.slot0 >= 0 && z.len0 == T;
-            else if (z.n == 2) ok = z.slot0 >= 0 && z.slot1 >= 0 && z.slot0 != z.slot1 && z.q0 == 0 && z.len0 >= 1 && z.t1 == z.len0 && z.len0 + z.len1 == T;
-            else ok = false;
-        }
-    for (long long j = 0; j < W && ok; ++j) if (next_step[(size_t)j] != T) ok = false;
+    }
+    for (long long j = 0; j < W && ok; ++j) {
+        const Seen &z = seen[(size_t)j];
+        if (z.n == 1) ok = z.slot0 >= 0 && z.len0 == T;
+        else if (z.n == 2) ok = z.slot0 >= 0 && z.slot1 >= 0 && z.slot0 != z.slot1 && z.q0 == 0 && z.len0 >= 1 && z.t1 == z.len0 && z.len0 + z.len1 == T;
+        else ok = false;
+    }
     if (!ok) return remember(0, nullptr);
-    // One table row per WAVEFRONT of a launch, not per slot: a launch of S slots has ceil(S / kWavesPerBlock) whole workgroups, and the
+    // One table row per WAVEFRONT of the launch, not per slot: a launch of S slots has ceil(S / kWavesPerBlock) whole workgroups, and the
     // wavefronts past slot S - 1 of the last one read rows too -- theirs are all-zero (no steps).  (Round 3, first GPU run: with rows
-    // per slot those wavefronts read the next launch's rows, or past the allocation for the last launch: a memory fault at S = 26.)
+    // per slot those wavefronts read past the allocation: a memory fault at S = 26.)
     const long long Sp = rot_padded_slots(S);
-    std::vector<int4> table((size_t)(D * Sp * kSchedPieces), int4{0, 0, 0, 0});
-    for (long long k = 0; k < D; ++k)
-        for (long long sl = 0; sl < S; ++sl) {
-            const auto &c = cell[(size_t)(k * S + sl)];
-            for (size_t q = 0; q < c.size(); ++q) {
-                int bits = 0;
-                if (one_launch) {
-                    if (c[q].t0 > 0) bits |= SCHED_WAIT;
-                    if (c[q].t0 + c[q].nt < T && !h->drop_publish) bits |= SCHED_PUBLISH;
-                }
-                table[(size_t)((k * Sp + sl) * kSchedPieces) + q] = int4{c[q].ew, c[q].t0, c[q].nt, bits};
-            }
+    std::vector<int4> table((size_t)(Sp * kSchedPieces), int4{0, 0, 0, 0});
+    for (long long sl = 0; sl < S; ++sl) {
+        const auto &c = cell[(size_t)sl];
+        for (size_t q = 0; q < c.size(); ++q) {
+            int bits = 0;
+            if (c[q].t0 > 0) bits |= SCHED_WAIT;
+            if (c[q].t0 + c[q].nt < T && !h->drop_publish) bits |= SCHED_PUBLISH;
+            table[(size_t)(sl * kSchedPieces) + q] = int4{c[q].ew, c[q].t0, c[q].nt, bits};
         }
+    }
     int4 *dev = nullptr;
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
     if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }
-    return remember((int)D, dev);
+    return remember(1, dev);
 }
 
 extern "C" int uavenv_step_many_prepare(uavenv_t *h, int n_steps) {
@@ -736,11 +702,8 @@ static int launch_many(uavenv_t *h, KParams &p, int n_steps, hipStream_t s) {
     const int i = rotation_plan(h, n_steps, s);        // (first use of this n_steps outside a capture: builds + uploads the table, synchronously)
     if (i >= 0) {
         const uavenv::RotPlan pl = (*h->rot_plans)[(size_t)i];
-        for (int k = 0; k < pl.n_launches; ++k) {
-            p.sched = pl.dev + (size_t)k * (size_t)rot_padded_slots(pl.slots) * kSchedPieces;
-            if (int rc = launch_env<MODE_STEP, MANY_>(h, p, s, pl.slots)) return rc;
-        }
-        return UAVENV_OK;
+        p.sched = pl.dev;
+        return launch_env<MODE_STEP, MANY_>(h, p, s, pl.slots);
     }
     p.sched = nullptr;
     return launch_env<MODE_STEP, MANY_>(h, p, s);

@@ -218,9 +218,9 @@ int uavenv_step_many_prepare(uavenv_t *h, int n_steps);
 
 /* Test hook: how uavenv_step_many / uavenv_step_many_packed would run n_steps on this handle: *n_launches = 0 for the plain single
  * launch, else the number of launches of the rotation schedule (1 = the one-launch schedule with hand-offs
- * between wavefronts) and *slots wavefronts per launch.  Environment, read once in uavenv_create: UAVENV_ROTATE=0 never rotate,
- * =1 the one-launch schedule whenever a valid one exists, =2 the several-launch schedule of ABI 4 whenever a valid one exists
- * (A/B runs); UAVENV_ROTATE_SLOTS=k plan as if the device had k SIMDs (lets small batches exercise the schedule);
+ * between wavefronts; the several-launch schedule of ABI 4 is gone) and *slots wavefronts per launch.  Environment, read once in
+ * uavenv_create: UAVENV_ROTATE=0 never rotate, =1 rotate whenever a valid schedule exists; UAVENV_ROTATE_SLOTS=k plan as if the
+ * device had k SIMDs (lets small batches exercise the schedule);
  * UAVENV_HANDOFF_SPIN_US=n spin budget of one hand-off wait (default 2 000 000); UAVENV_DEBUG_DROP_PUBLISH=1 builds schedules
  * whose hand-offs are never signalled (the time-out path's test). */
 int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots);

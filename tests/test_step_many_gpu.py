@@ -102,21 +102,19 @@ ROT_SHAPES = [(100, 4, 20, 7, 24), (100, 4, 20, 50, 26), (301, 4, 20, 33, 80), (
               (100, 4, 20, 21, 13), (301, 4, 20, 40, 29), (64, 4, 20, 12, 5)]      # k = 2, 3, 4 resident wavefronts per pretend-SIMD
 
 
-@pytest.mark.parametrize("form", ["1", "2"], ids=["one_launch", "several_launches"])
 @pytest.mark.parametrize("packed_out", [False, True], ids=["nine_arrays", "packed_records"])
 @pytest.mark.parametrize("shape", ROT_SHAPES, ids=lambda s: "%denv_%dx%d_T%d_S%d" % s)
-def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, form, monkeypatch):
-    """A multi-step call on S < W < 2 S wavefronts runs as S persistent wavefronts, each working through up to three pieces
+def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, monkeypatch):
+    """A multi-step call on S < W < 2 S wavefronts runs as ONE launch of S persistent wavefronts, each working through up to three pieces
     (env-wavefront, first step, steps) of a wrap-around schedule (csrc/uavenv_capi.hip: rotation_plan); the two wavefronts that share
-    a split job hand its state over through memory + a flag (form 1, one launch), or the schedule is cut into several launches and stream
-    order does it (form 2, round 3).  Same steps, same order per env: every output of every step and the final state must equal the
+    a split job hand its state over through memory + a flag.  Same steps, same order per env: every output of every step and the final state must equal the
     single plain launch.  UAVENV_ROTATE_SLOTS makes small batches plan as if the device had that few SIMDs; at BASELINE's 4096 envs
     the schedule is chosen automatically (tests/test_full_size_parity_gpu.py compares that run with the oracle)."""
     torch = _torch()
     import ctypes as C
 
     n, n_bs, n_ue, T, slots = shape
-    monkeypatch.setenv("UAVENV_ROTATE", form)
+    monkeypatch.setenv("UAVENV_ROTATE", "1")
     monkeypatch.setenv("UAVENV_ROTATE_SLOTS", str(slots))
     env = _env(n, n_bs, n_ue)
     monkeypatch.setenv("UAVENV_ROTATE", "0")
@@ -125,7 +123,7 @@ def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_ou
     nl, sl = C.c_int(-1), C.c_longlong(-1)
     assert env._lib.uavenv_debug_rotation_info(env._h, T, C.byref(nl), C.byref(sl)) == 0
     assert sl.value == (W // slots) * slots, (nl.value, sl.value)
-    assert (nl.value == 1) if form == "1" else (nl.value >= 2), nl.value       # the rotated handle really rotates ...
+    assert nl.value == 1, nl.value                                              # the rotated handle really rotates ...
     assert ref._lib.uavenv_debug_rotation_info(ref._h, T, C.byref(nl), C.byref(sl)) == 0 and nl.value == 0    # ... the reference does not
     act = _actions(torch, env, T, 8)
     for rep in range(3):                                                        # later calls: cached schedule, flags cleared by their consumers

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Round-4 A/B of uavenv_step_many's three launch forms, interleaved in one process on one box:
-   plain (one launch, wavefront w = env-wavefront w), one-launch rotation (S persistent wavefronts with hand-offs, UAVENV_ROTATE=1),
-   several-launch rotation (round 3, UAVENV_ROTATE=2) -- for each (n_envs, steps per call) pair asked for.
+"""Round-4 A/B of uavenv_step_many's launch forms, interleaved in one process on one box:
+   plain (one launch, wavefront w = env-wavefront w) and one-launch rotation (S persistent wavefronts with hand-offs, UAVENV_ROTATE=1)
+   -- for each (n_envs, steps per call) pair asked for.  (profiles/r04a_* also has round 3's several-launch form, removed since.)
    us per call from HIP events around `reps` back-to-back calls, and a single-call figure (one call between two synchronises: what a
    20-step timed region sees).  Prints one JSON object.   usage: r04_many_ab.py [n_envs:T ...]"""
 import json
@@ -46,7 +46,7 @@ def main():
     legs = {}
     for n, T in pairs:
         tape = torch.randint(0, 625, (T, n), generator=g, dtype=torch.int64).to(dev)
-        for form, val in (("plain", "0"), ("rot_one_launch", "1"), ("rot_several_launches", "2")):
+        for form, val in (("plain", "0"), ("rot_one_launch", "1")):
             os.environ["UAVENV_ROTATE"] = val                                  # read once per handle, in uavenv_create
             e = BatchedMobiEnv(n, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5], device=dev, seed=0x5EED)
             os.environ.pop("UAVENV_ROTATE")
