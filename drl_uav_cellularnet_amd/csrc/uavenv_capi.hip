@@ -611,11 +611,14 @@ static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
     };
     const long long M = (W * T + S - 1) / S;                       // makespan in step-times
     if (M - T < 1 || M >= 2 * (long long)T) return remember(0, nullptr);
-    // Automatic use only where it pays.  One wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take
-    // (2.77 vs 4.31 us at 4096 envs), and the pinned kernel keeps at most two wavefronts resident per SIMD: k <= 2, W / S <= 1.45.
-    // A hand-off costs its two wavefronts a state store + release and a poll + acquire + state load (a 20-step call: 97.7 us plain,
-    // 91.0 us with the schedule, 75 us of it the steps), against ~0.6 us gained per step: from 16 steps per call on.
-    if (h->rotate == -1 && (k_res > 2 || 100 * W > 145 * S || T < 16)) return remember(0, nullptr);
+    // Automatic use only where it pays (same-box sweeps, us per step plain -> scheduled: profiles/r04a_*, r04k_many_ab_sweep.json).
+    // k = 1: one wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take (2.77 vs 4.31 us), so the schedule
+    // wins while W / S <= 1.45 (4096 envs, 1.33: 4.60 -> 3.81; 5400 envs, 1.76: 4.65 -> 4.90).  k = 2: the plain launch of more than two
+    // wavefronts per SIMD is the unpinned kernel with a third wavefront queued behind two resident ones; 2 k-resident pinned wavefronts win
+    // over the whole range (8192 envs: 7.90 -> 5.92; 9000 envs, 1.46: 7.90 -> 6.47).  k > 2 would need more than two resident wavefronts of
+    // the pinned kernel.  Every piece border costs its slot a state store (+ release) and a (poll + acquire +) state load, ~5-8 us, against
+    // ~0.7 us gained per step: 16-step calls lose (4.98 -> 5.23), 20-step calls win (4.87 -> 4.52): from 20 steps per call on.
+    if (h->rotate == -1 && (k_res > 2 || (k_res == 1 && 100 * W > 145 * S) || T < 20)) return remember(0, nullptr);
     struct Piece { int ew, t0, nt; long long time; };
     std::vector<std::vector<Piece>> cell((size_t)S);              // [slot] -> pieces
     bool ok = true;

@@ -72,7 +72,7 @@ def main():
                 continue                              # (the scratch-env pre-warm's single steps: described by the seq passes)
             cc = c[k]
             if many:
-                calls_pmc, calls_tr = pmc_steps // spc, trace_steps // spc
+                calls_pmc, calls_tr = pmc_steps // spc + rn.get("prewarm_calls", 0), trace_steps // spc + rn.get("prewarm_calls", 0)
             else:
                 calls_pmc, calls_tr = cc["FETCH_SIZE"][0], st[k][0]        # one dispatch per call
             dpc = cc["FETCH_SIZE"][0] / float(calls_pmc)
