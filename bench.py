@@ -408,28 +408,38 @@ class EnvRun:
                 self.t = 0
 
 
-def timed(fn, dist, dev):
-    """synchronize + barrier, clock, K steps, synchronize, clock, barrier; HIP events on the launch stream inside -> (wall s, gpu ms)."""
+def timed(fn, dist, dev, keep_busy=None, events=True):
+    """synchronize + barrier, clock, K steps, synchronize, clock, barrier; HIP events on the launch stream inside -> (wall s, gpu ms).
+    keep_busy: untimed device work (on a scratch env) queued right before the opening synchronize, so that the region starts microseconds
+    after the device was last busy -- a 0.1-ms region that starts on a device left idle for milliseconds of host work measures the clock
+    ramp, not the kernel."""
     import torch
 
     import gc
 
     gc.disable()                                # no collector pause inside a region that may last 0.1 ms (and no gc.collect() here:
                                                 # tens of ms of host work would let the device idle and clock down before the region)
+    if keep_busy is not None:
+        keep_busy()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # events=False: nothing but the K steps between the two clock readings.  A pair of HIP events around a 20-step call -- two marker
+    # packets on the launch stream, or start / stop events on the dispatch itself -- costs the region 9-10 us of ~110 (tools/region_overhead.py,
+    # profiles/r04o_region_overhead.json); the caller then takes the kernel's duration from a repeat of the same launches (measure_env).
+    ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if events else (None, None)
     t0 = time.perf_counter()
-    ev0.record()
+    if events:
+        ev0.record()
     fn()
-    ev1.record()
+    if events:
+        ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0      # this rank's K steps are complete; the slowest rank's time is what is reported (MAX)
     gc.enable()
     if dist is not None:
         dist.barrier()                      # closing bracket: nobody leaves before everybody has finished (not part of any rank's clock:
-    return elapsed, ev0.elapsed_time(ev1)   # an RCCL barrier costs tens of microseconds, a 20-step region lasts 0.1 ms)
+    return elapsed, (ev0.elapsed_time(ev1) if events else None)   # an RCCL barrier costs tens of microseconds, a 20-step region lasts 0.1 ms)
 
 
 def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=None):
@@ -472,11 +482,29 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
     from drl_uav_cellularnet_amd import _capi
 
     census0 = _capi.launch_census()
-    elapsed, gpu_ms = timed(go, dist, dev)
+    busy = None
+    if scratch is not None:
+        def busy():                              # ~0.5 ms of single steps on the scratch env (the measured env is not touched)
+            for t in range(64):
+                scratch.step(pool[t % n_pool])
+    many = launch in ("many", "manypk")
+    elapsed, gpu_ms = timed(go, dist, dev, keep_busy=busy, events=not many)
     kernels = launched_kernels(census0, _capi.launch_census())          # the instantiation(s) the timed region really launched
     bad = [r for r in results if isinstance(r, int) and r != 0]          # return codes of the bound C-ABI launches
     if bad:
         _capi.check(bad[0])
+    launch_us = None
+    if many:
+        # The multi-step kernel's own duration: the SAME K steps once more, every dispatch carrying its start / stop events
+        # (uavenv_launch_timing: hipExtLaunchKernelGGL, the dispatch packet's timestamps) -- live in this process, on the launch stream,
+        # but outside the wall-clock region above, which therefore holds nothing but the K steps.
+        env.launch_timing(True)
+        for f in r.compile(K):
+            f()
+        torch.cuda.synchronize()
+        launch_us = env.launch_times_us()
+        env.launch_timing(False)
+        gpu_ms = sum(launch_us) * 1e-3                                   # device time of the K steps' launches (tape copies / resets excluded)
     per_rank = gather_over_ranks([elapsed, gpu_ms], device=reduce_dev)   # every rank's own clock: a straggler must be visible
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
     sched = None
@@ -487,7 +515,8 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         env._lib.uavenv_debug_rotation_info(env._h, min(ck, K), C.byref(nl), C.byref(sl))
         sched = {"form": SCHEDULE_NAMES.get(nl.value, "?"), "dispatches_per_call": max(1, nl.value), "wavefronts_per_dispatch": sl.value or None}
     return elapsed, gpu_ms, {"kernels": kernels, "per_rank_elapsed_s": [p[0] for p in per_rank],
-                             "per_rank_gpu_ms": [p[1] for p in per_rank], "schedule": sched, "device_error": env.device_error()}
+                             "per_rank_gpu_ms": [p[1] for p in per_rank], "schedule": sched, "device_error": env.device_error(),
+                             "launch_us": launch_us}
 
 
 def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollout_len=A2C_ROLLOUT):
@@ -770,6 +799,10 @@ def main(argv=None):
                 "algorithmic_bytes_per_env_step": b_step,
                 "algorithmic_bytes_per_launch": b_step * E * spl,
                 "avg_launch_us": per_step_s * 1e6 * spl,
+                "avg_launch_us_is": ("mean over the %d launch(es) of a REPEAT of the timed region's K steps, each dispatch carrying its own start / stop "
+                                     "events (uavenv_launch_timing); the wall-clock region itself holds no events (they cost a 20-step region 9-10 us)"
+                                     % len(info["launch_us"])) if info.get("launch_us") else "HIP events on the launch stream around the timed region",
+                "launch_us": info.get("launch_us"),
                 "avg_step_us": per_step_s * 1e6,
                 "transcendental_evals_per_step": transcendental_evals_per_env_step(n_ue, n_bs) * E,
                 "transcendental_evals_per_s": transcendental_evals_per_env_step(n_ue, n_bs) * E / per_step_s}

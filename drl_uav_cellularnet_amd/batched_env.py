@@ -290,6 +290,17 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_device_error(self._h, C.byref(code)))
         return int(code.value)
 
+    def launch_timing(self, enable=True):
+        """Attach start / stop events to the following multi-step dispatches themselves (uavenv_launch_timing); see launch_times_us()."""
+        _capi.check(self._lib.uavenv_launch_timing(self._h, 1 if enable else 0))
+
+    def launch_times_us(self):
+        """Durations (us) of the step_many / step_many_packed launches since launch_timing(True), in issue order (waits for them)."""
+        buf = (C.c_double * 256)()
+        n = C.c_int(0)
+        _capi.check(self._lib.uavenv_launch_times_us(self._h, buf, 256, C.byref(n)))
+        return [buf[i] for i in range(min(n.value, 256))]
+
     def step_many(self, actions, out=None, refresh_out=True):
         """T consecutive step() calls in ONE launch (uavenv_step_many) for actions that do not depend on the observations in
         between: ``actions`` int64 [T, N] on this device.  Returns a dict of [T, ...] tensors (block t = what step t returned;

@@ -1,6 +1,7 @@
 // C ABI of libuavenv (include/uavenv.h): handle management, state blob, kernel dispatch.
 // gfx950 only; built by drl_uav_cellularnet_amd/build.py with hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cmath>
@@ -44,12 +45,17 @@ struct uavenv {
     uint32_t *err_host, *err_dev;   // sticky device-side error word: host-mapped memory, so that every entry point can test it without a HIP call
     uint32_t spin_us;   // hand-off spin budget (UAVENV_HANDOFF_SPIN_US, default 2 s)
     int drop_publish;   // UAVENV_DEBUG_DROP_PUBLISH=1 (test hook): schedules are built WITHOUT their publish bits, so every hand-off times out
+    // uavenv_launch_timing: start / stop events attached to the multi-step dispatches themselves (hipExtLaunchKernelGGL: the timestamps of
+    // the dispatch packet, no marker packets around it), a ring of kTimedLaunches pairs
+    std::vector<hipEvent_t> *tev;
+    int timing, n_timed;
     char *scratch_out;  // multi-pass handles, uavenv_step_many_packed: one step's nine output arrays (allocated on first use)
     int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
 };
 
+constexpr int kTimedLaunches = 256;
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string &msg) {
@@ -85,6 +91,37 @@ static int poisoned(const uavenv *h, const char *what) {
                       "wavefronts timed out); its state is incomplete -- uavenv_set_state() or a new handle", what, *(volatile uint32_t *)h->err_host);
         return fail(UAVENV_E_DEVICE, buf);
     }
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_launch_timing(uavenv_t *h, int enable) {
+    if (!h) return fail(UAVENV_E_INVALID, "launch_timing: null handle");
+    DeviceGuard guard(h->device);
+    if (enable && !h->tev) {
+        h->tev = new (std::nothrow) std::vector<hipEvent_t>();
+        if (!h->tev) return fail(UAVENV_E_NOMEM, "launch_timing: host allocation failed");
+        for (int i = 0; i < 2 * kTimedLaunches; ++i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return fail(UAVENV_E_HIP, "launch_timing: hipEventCreate failed");
+            h->tev->push_back(e);
+        }
+    }
+    h->timing = enable ? 1 : 0;
+    h->n_timed = 0;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_launch_times_us(uavenv_t *h, double *us_out, int max_out, int *n_out) {
+    if (!h || !n_out || (max_out > 0 && !us_out)) return fail(UAVENV_E_INVALID, "launch_times_us: null argument");
+    DeviceGuard guard(h->device);
+    const int n = h->n_timed < max_out ? h->n_timed : max_out;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize((*h->tev)[(size_t)i * 2 + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, (*h->tev)[(size_t)i * 2], (*h->tev)[(size_t)i * 2 + 1]));
+        us_out[i] = (double)ms * 1e3;
+    }
+    *n_out = h->n_timed;
     return UAVENV_OK;
 }
 
@@ -310,6 +347,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
     if (h->scratch_out) (void)hipFree(h->scratch_out);
+    if (h->tev) { for (hipEvent_t e : *h->tev) (void)hipEventDestroy(e); delete h->tev; }
     if (h->sched_flag_dev) (void)hipFree(h->sched_flag_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
     if (h->rot_plans) {
@@ -462,6 +500,11 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
+        if (MANY && tev0 != nullptr) {   /* (multi-step launches with uavenv_launch_timing on: events on the dispatch itself) */ \
+            if (pin) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);     \
+            else if (fast) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS); \
+            else hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);       \
+        } else                                                                                                   \
         if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);     \
         else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS); \
         else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);       \
@@ -483,6 +526,11 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
         }                                                                                                        \
     } while (0)
     bool counted = false;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    if (MANY && h->timing && h->tev && h->n_timed < kTimedLaunches) {
+        tev0 = (*h->tev)[(size_t)h->n_timed * 2]; tev1 = (*h->tev)[(size_t)h->n_timed * 2 + 1];
+        h->n_timed += 1;
+    }
     switch (h->bt) {
         case 4: UAVENV_LAUNCH(4); break;
         case 8: UAVENV_LAUNCH(8); break;
@@ -670,13 +718,16 @@ static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
     std::vector<int4> table((size_t)(Sp * kSchedPieces), int4{0, 0, 0, 0});
     for (long long sl = 0; sl < S; ++sl) {
         const auto &c = cell[(size_t)sl];
-        for (size_t q = 0; q < c.size(); ++q) {
-            int bits = 0;
-            if (c[q].t0 > 0) bits |= SCHED_WAIT;
-            if (c[q].t0 + c[q].nt < T && !h->drop_publish) bits |= SCHED_PUBLISH;
-            table[(size_t)(sl * kSchedPieces) + q] = int4{c[q].ew, c[q].t0, c[q].nt, bits};
+        for (size_t q = 0; q < c.size(); ++q) {         // column by kind: 0 publishes (it is the slot's first piece, verified above), 1 whole, 2 waits
+            int bits = 0, col = 1;
+            if (c[q].t0 > 0) { bits |= SCHED_WAIT; col = 2; }
+            if (c[q].t0 + c[q].nt < T) { col = 0; if (!h->drop_publish) bits |= SCHED_PUBLISH; }
+            int4 &cellq = table[(size_t)(sl * kSchedPieces) + (size_t)col];
+            if (cellq.z != 0) ok = false;                // (two pieces of one kind in a slot: cannot happen for M < 2 T)
+            cellq = int4{c[q].ew, c[q].t0, c[q].nt, bits};
         }
     }
+    if (!ok) return remember(0, nullptr);
     int4 *dev = nullptr;
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
     if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }

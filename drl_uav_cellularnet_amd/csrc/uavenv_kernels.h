@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "intdiv.h"
 #include "lean_math.h"
@@ -150,6 +151,41 @@ template <class T> __device__ __forceinline__ T ldx(const T *base, uint32_t idx)
 template <class T, class V> __device__ __forceinline__ void stx(T *base, uint32_t idx, V v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + idx * (uint32_t)sizeof(T)) = (T)v;
 }
+// The same accesses made COHERENT at agent scope (hand-off pieces of a one-launch schedule): relaxed agent-scope atomics, i.e.
+// global_load / global_store ... sc1 in 8-byte (4-byte) pieces.  Such a load bypasses this CU's L1 and is served by the L2 / the
+// coherence point; such a store is written through.  A record moved this way needs no release / acquire FENCE around it: the
+// producer waits for its stores (s_waitcnt vmcnt(0)) before it sets the flag, the consumer loads only after its poll has seen the flag
+// (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> asm vmcnt(0) -> sc1 flag; every load of the handed-off bytes an sc1 load).
+// Measured before building it: the two fences cost a 20-step call 6 us of 91 (profiles/r04l_fence_cost.json).
+template <bool COH, class T> __device__ __forceinline__ T ldx_c(const T *base, uint32_t idx) {
+    if (!COH) return ldx(base, idx);
+    const char *q = reinterpret_cast<const char *>(base) + idx * (uint32_t)sizeof(T);
+    union U { T t; unsigned long long w[(sizeof(T) + 7) / 8]; uint32_t d[(sizeof(T) + 3) / 4]; __device__ U() {} } u;
+    if (sizeof(T) % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / 8); ++i)
+            u.w[i] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        static_assert(sizeof(T) % 8 == 0 || sizeof(T) == 4, "coherent access: 4-byte or 8-byte-multiple records");
+        u.d[0] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return u.t;
+}
+template <bool COH, class T, class V> __device__ __forceinline__ void stx_c(T *base, uint32_t idx, V v) {
+    if (!COH) { stx(base, idx, v); return; }
+    char *q = reinterpret_cast<char *>(base) + idx * (uint32_t)sizeof(T);
+    union U { T t; unsigned long long w[(sizeof(T) + 7) / 8]; uint32_t d[(sizeof(T) + 3) / 4]; __device__ U() {} } u;
+    u.t = (T)v;
+    if (sizeof(T) % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / 8); ++i)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(q) + i, u.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        static_assert(sizeof(T) % 8 == 0 || sizeof(T) == 4, "coherent access: 4-byte or 8-byte-multiple records");
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(q), u.d[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // An index for the stores of ONE basic block.  Without it hipcc hoists base + zext(offset) of a store into the kernel prologue
 // (v_lshl_add_u64 sgpr_base, vgpr_offset), keeps every such 64-bit address alive in a VGPR pair across the whole compute phase
 // and, selecting instructions block by block, can no longer fold it into the SGPR-base form at the store.  The empty asm
@@ -564,7 +600,7 @@ __device__ __forceinline__ void fifo_handover(const HotConst &H, int depth, int 
 // the trace modes, depth and step count during warm-up), and the whole record goes back with one 32-byte store.
 // `o`: where this step's outputs go (p.out, or the current step's block of a multi-step launch).  REC = false: outputs only
 // (steps 0 .. T-2 of a multi-step launch; the record is stored once, after the last step).
-template <int MODE, bool FAST, bool REC = true, bool OUTS = true>
+template <int MODE, bool FAST, bool REC = true, bool OUTS = true, bool COH = false>
 __device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, const StatePtrs &st, uint32_t e, EnvRec rec, uint32_t tick,
                                            int agg, int deagg, int depth, int step_n, double sum_cur, int n_outage) {
     rec.tick = tick;
@@ -598,7 +634,7 @@ __device__ __forceinline__ void env_finish(const KParams &p, const OutPtrs &o, c
         if (OUTS && UAV_OUT64(o.mean_sinr_f64)) stx(o.mean_sinr_f64, e, mean);
         if (OUTS && UAV_OUT(o.n_out)) stx(o.n_out, e, n_outage);
     }
-    if (REC) stx(st.env, e, rec);
+    if (REC) stx_c<COH>(st.env, e, rec);
 }
 
 // Multi-step launches (uavenv_step_many): every output array holds one block per step, [T][...]; the pointers move on by one
@@ -710,10 +746,13 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // trip and state store, i.e. the fixed ~5.8 us a 4096-env launch spends outside its arithmetic.
 // The kernel proper: `ew` = the env-wavefront this wavefront hosts (envs ew*EPW .. ew*EPW+EPW-1), `t0` / `nt` = first step and
 // number of steps (multi-step launches; a plain launch runs env-wavefront = hardware wavefront and all of p.n_ticks).
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, bool PKO>
+// HO (pieces of a one-launch schedule): bit 0 = this piece continues a job another wavefront started (state LOADED coherently),
+// bit 1 = another wavefront continues this piece's job (state STORED coherently); 0 everywhere else.
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, bool PKO, int HO = 0>
 __device__ __forceinline__ void env_packed_body(char *blob, const long long *actions, const int8_t *gid_of_u, long long N, int U, int EPW,
                                                 int Gr, int B_rt, int lane_magic, const KParams &p, int (*s_bs)[kMaxEpw][2 * kMaxBs],
                                                 const int wave, const long long ew, const int t0, const int nt, const int e_lo, const int e_hi) {
+    constexpr bool LDC = (HO & 1) != 0, STC = (HO & 2) != 0;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
@@ -757,35 +796,35 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
             const uint32_t c0 = is_reset(MODE) ? 0u : e32 * (uint32_t)B;                 // mobile_env.py:119 on reset
 #pragma unroll
             for (int b = 0; b < BT; ++b)
-                if (b < B) { const int2 q = ldx(cells, c0 + (uint32_t)b); bsx[b] = q.x; bsy[b] = q.y; }
+                if (b < B) { const int2 q = is_reset(MODE) ? ldx(cells, c0 + (uint32_t)b) : ldx_c<LDC>(cells, c0 + (uint32_t)b); bsx[b] = q.x; bsy[b] = q.y; }
             if (is_step(MODE)) act = ldx(actions, e32);
         } else if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }
-            else { const int2 q = ldx(reinterpret_cast<const int2 *>(st.bs_xy), ib32); bx = q.x; by = q.y; }
+            else { const int2 q = ldx_c<LDC>(reinterpret_cast<const int2 *>(st.bs_xy), ib32); bx = q.x; by = q.y; }
             if (is_step(MODE)) { act = ldx(actions, e32); apw = p.act_pow[ul]; }
         }
     }
-    const EnvRec erec = ldx(st.env, e32);                      // tick, phase counters, FIFO depth, step count: one record
+    const EnvRec erec = ldx_c<LDC>(st.env, e32);                      // tick, phase counters, FIFO depth, step count: one record
     uint32_t tick = erec.tick;
     int agg = erec.agg, deagg = erec.deagg;
     int depth = erec.fifo_depth;      // (advances only between the steps of a multi-step launch)
     int step_n = erec.step_n;
     double ogx = 0, ogy = 0, ogfl = 0, ogv = 0, ogc = 0, ogs = 0;
     if (gown) {
-        const GrpRec g = ldx(st.grp, ig32);
+        const GrpRec g = ldx_c<LDC>(st.grp, ig32);
         ogx = g.x; ogy = g.y; ogfl = g.fl; ogv = g.v; ogc = g.c; ogs = g.s;
     }
     double x = 0, y = 0, hu = 0, hu_inj = 0;
     int ix = 0, iy = 0, gid = 0;
     int serving = 0, r0 = 0, r1 = 0, r2 = 0;
     if (live) {                                                   // heading, integer cell, serving UAV and FIFO rows: one record
-        const UeAux a = ldx(st.ue_aux, iu32);
+        const UeAux a = ldx_c<LDC>(st.ue_aux, iu32);
         hu = a.hu; ix = a.ix; iy = a.iy; serving = a.serving; r0 = a.r0; r1 = a.r1; r2 = a.r2;
     }
     if (has_mobility(MODE)) {
         gid = ldx(gid_of_u, (uint32_t)u);                          // table padded to >= 64 entries: dead lanes have u < 64
         if (live) {
-            const UePos q = ldx(st.ue_pos, iu32);
+            const UePos q = ldx_c<LDC>(st.ue_pos, iu32);
             x = q.x; y = q.y;
             if (UAV_INJ(p.inj_theta)) hu_inj = p.inj_theta[iu];   // injected draws cover exactly one tick
         }
@@ -793,7 +832,7 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
         ix = p.trace_xy[2 * iu]; iy = p.trace_xy[2 * iu + 1];
     }
     unsigned long long prev_out = 0ull;
-    if (is_step(MODE)) prev_out = ldx(st.out_bits, e32);           // one 64-bit word per env here (U <= 64)
+    if (is_step(MODE)) prev_out = ldx_c<LDC>(st.out_bits, e32);           // one 64-bit word per env here (U <= 64)
 
     // Only now touch the parameter struct: its (cold) kernarg fetch overlaps the global loads issued above.
     __builtin_amdgcn_sched_barrier(0);
@@ -965,9 +1004,9 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
     // ================= store phase: state, then outputs ==========================================================
     if (live) {
         const uint32_t iw = block_local<!PIN>(iu32);
-        if (has_mobility(MODE)) stx(st.ue_pos, iw, UePos{x, y});
+        if (has_mobility(MODE)) stx_c<STC>(st.ue_pos, iw, UePos{x, y});
         // warm-up leaves serving and the FIFO rows as loaded; a reset overwrites serving and row 0 only (depth becomes 1)
-        stx(st.ue_aux, iw, UeAux{hu, (int16_t)ix, (int16_t)iy, (int8_t)serving, (int8_t)r0, (int8_t)r1, (int8_t)r2});
+        stx_c<STC>(st.ue_aux, iw, UeAux{hu, (int16_t)ix, (int16_t)iy, (int8_t)serving, (int8_t)r0, (int8_t)r1, (int8_t)r2});
         if (MODE != MODE_WARMUP && !MANY) {
             if (UAV_OUT(p.out.ue_xy)) { stx(p.out.ue_xy, 2u * iw, (int16_t)ix); stx(p.out.ue_xy, 2u * iw + 1u, (int16_t)iy); }
             if (UAV_OUT(p.out.serving)) stx(p.out.serving, iw, (int8_t)serving);
@@ -977,19 +1016,19 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
     }
     if (gown) {
         const uint32_t gw = block_local<!PIN>(ig32);
-        stx(st.grp, gw, GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs});
+        stx_c<STC>(st.grp, gw, GrpRec{ogx, ogy, ogfl, ogv, ogc, ogs});
     }
     if (bown) {
         const uint32_t bw = block_local<!PIN>(ib32);
-        stx(st.bs_xy, 2u * bw, bx); stx(st.bs_xy, 2u * bw + 1u, by);
+        stx_c<STC>(st.bs_xy, 2u * bw, bx); stx_c<STC>(st.bs_xy, 2u * bw + 1u, by);
         if (!MANY) { if (UAV_OUT(p.out.bs_xy)) { stx(p.out.bs_xy, 2u * bw, bx); stx(p.out.bs_xy, 2u * bw + 1u, by); } }
     }
     if (head) {
         const uint32_t ew = block_local<!PIN>(e32);
-        if (MODE != MODE_WARMUP) stx(st.out_bits, ew, ob);                                // :116 / :173
+        if (MODE != MODE_WARMUP) stx_c<STC>(st.out_bits, ew, ob);                                // :116 / :173
         // (MANY: outputs of the LAST step + the record; depth / step_n are the values that step started from)
-        if (PKO) env_finish<MODE, FAST, true, false>(p, p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);   // record only
-        else env_finish<MODE, FAST>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        if (PKO) env_finish<MODE, FAST, true, false, STC>(p, p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);   // record only
+        else env_finish<MODE, FAST, true, true, STC>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -1004,14 +1043,13 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
 }
 
 // ---- hand-off between the two wavefronts that share a split job of a one-launch schedule -----------------------------------------
-// Producer: its state stores are plain stores; they leave this wavefront (s_waitcnt vmcnt(0)), an agent-scope release writes the
-// XCD's L2 back, and only then the flag goes out (MI355X_MICROARCH.md, "Valid forms": the explicit wait between the release and the
-// flag store is the guide's fix for a compiler pass that drops it).  Consumer: ONE lane polls with relaxed agent-scope loads (they
-// bypass the CU's L1), then an agent-scope acquire invalidates what this CU may hold of the state, then the body's plain loads.
-// The flag is cleared by its consumer, so a captured launch replays correctly and no per-call epoch is needed.
+// The state of the job crosses in coherent accesses (ldx_c / stx_c above: the publishing piece stores it write-through, the waiting
+// piece loads it past its L1), so the hand-off itself is: producer -- its stores have left (s_waitcnt vmcnt(0)), then the flag;
+// consumer -- ONE lane polls the flag with relaxed agent-scope loads, bounded; the state loads are issued after the poll has seen it.
+// No agent-scope release / acquire fence (an L2 write-back and an L1 invalidate: 6 us of a 91-us 20-step call,
+// profiles/r04l_fence_cost.json).  The flag is cleared by its consumer, so a captured launch replays correctly and no per-call epoch
+// is needed.
 __device__ __forceinline__ void sched_hand_off_publish(const KParams &p, int ew) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.sched_flag + ew, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1033,8 +1071,7 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.sched_err, kDevErrHandoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");                       // (the state loads below stay below the poll)
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
     return true;
 }
@@ -1070,17 +1107,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         // waits until the wavefront that ran the job's first steps has published them; a piece that ends inside a job
         // (SCHED_PUBLISH) publishes.  Publishing pieces come FIRST in their slot and wait for nothing, so every wait ends once its
         // producer has been scheduled; the wait is bounded all the same (sched_hand_off_wait): a bug becomes an error code, not a hang.
-#pragma unroll
-        for (int q = 0; q < kSchedPieces; ++q) {
-            const int4 d = sched[gw * kSchedPieces + q];                      // uniform address
+        // Column q of a slot's table row: 0 = the piece that publishes (first steps of a split job: coherent stores), 1 = a whole job,
+        // 2 = the piece that waits (last steps of a split job: coherent loads); nt = 0 = no such piece in this slot.
+        auto piece = [&](auto q_c) {
+            constexpr int Q = decltype(q_c)::value;
+            const int4 d = sched[gw * kSchedPieces + Q];                      // uniform address
             const int ew = __builtin_amdgcn_readfirstlane(d.x), t0 = __builtin_amdgcn_readfirstlane(d.y);
             const int nt = __builtin_amdgcn_readfirstlane(d.z), bits = __builtin_amdgcn_readfirstlane(d.w);
-            if (nt <= 0) continue;
-            if (q > 0) __builtin_amdgcn_wave_barrier();                       // (the previous piece's reads of the LDS row are done)
-            if (bits & SCHED_WAIT) { if (!sched_hand_off_wait(p, ew)) return; }
-            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, ew, t0, nt, e_lo, e_hi);
-            if (bits & SCHED_PUBLISH) sched_hand_off_publish(p, ew);
-        }
+            if (nt <= 0) return true;
+            if (Q > 0) __builtin_amdgcn_wave_barrier();                       // (the previous piece's reads of the LDS row are done)
+            if (Q == 2) { if (!sched_hand_off_wait(p, ew)) return false; }
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO, (Q == 0 ? 2 : (Q == 2 ? 1 : 0))>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs,
+                                                                                                  wave, ew, t0, nt, e_lo, e_hi);
+            if (Q == 0 && (bits & SCHED_PUBLISH)) sched_hand_off_publish(p, ew);
+            return true;
+        };
+        if (!piece(std::integral_constant<int, 0>{})) return;
+        if (!piece(std::integral_constant<int, 1>{})) return;
+        if (!piece(std::integral_constant<int, 2>{})) return;
     }
 }
 

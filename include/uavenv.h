@@ -26,7 +26,8 @@ extern "C" {
 #define UAVENV_ABI_VERSION 5   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
                                 * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
                                 *      uavenv_step_many_prepare;
-                                * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs), uavenv_step_range */
+                                * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs), uavenv_step_range,
+                                *      uavenv_launch_timing / uavenv_launch_times_us */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -224,6 +225,14 @@ int uavenv_step_many_prepare(uavenv_t *h, int n_steps);
  * UAVENV_HANDOFF_SPIN_US=n spin budget of one hand-off wait (default 2 000 000); UAVENV_DEBUG_DROP_PUBLISH=1 builds schedules
  * whose hand-offs are never signalled (the time-out path's test). */
 int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long long *slots);
+
+/* Duration of the multi-step launches themselves, for callers that time SHORT calls (bench.py's 20-step region lasts 0.1 ms: a pair of
+ * HIP events recorded on the stream around the call are two marker packets that cost it 10 us).  uavenv_launch_timing(h, 1) makes every
+ * following uavenv_step_many / _packed dispatch carry its own start / stop events (hipExtLaunchKernelGGL: the dispatch packet's
+ * timestamps); uavenv_launch_times_us returns the durations of the up-to-256 launches since then in issue order (it waits for them),
+ * *n_out = how many were launched.  uavenv_launch_timing(h, 0) switches back to plain launches.  Not capturable. */
+int uavenv_launch_timing(uavenv_t *h, int enable);
+int uavenv_launch_times_us(uavenv_t *h, double *us_out, int max_out, int *n_out);
 
 /* Sticky device-side error of a handle: *code = 0, or the word a kernel left when it gave up (0x48414e44 "HAND": a wavefront of a
  * one-launch schedule waited longer than the spin budget for the wavefront that runs the first steps of the same envs -- never seen
