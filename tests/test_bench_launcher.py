@@ -81,12 +81,14 @@ def test_segment_plan_cuts_at_resets():
         cfg = _Cfg()
 
     r = bench.EnvRun.__new__(bench.EnvRun)
-    r.max_step, r.t = 250, 0
+    r.max_step, r.t, r.chunk = 250, 0, bench.CHUNK
     assert r.plan(20) == [(20, False)]
     assert r.plan(250) == [(100, False), (100, False), (50, True)]
     assert r.plan(300) == [(100, False), (100, False), (50, True), (50, False)]
     assert r.plan(120, t0=200) == [(50, True), (70, False)]
     assert sum(n for n, _ in r.plan(1999, t0=7)) == 1999
+    r.chunk = 20                                       # bench.py --chunk 20 (the profiling passes of the driver's 20-step launch shape)
+    assert r.plan(50) == [(20, False), (20, False), (10, False)] and r.plan(30, t0=240) == [(10, True), (20, False)]
 
 
 @pytest.mark.gpu
