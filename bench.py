@@ -490,6 +490,10 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
     many = launch in ("many", "manypk")
     elapsed, gpu_ms = timed(go, dist, dev, keep_busy=busy, events=not many)
     kernels = launched_kernels(census0, _capi.launch_census())          # the instantiation(s) the timed region really launched
+    if many:                                                             # (the keep-busy single steps on the scratch env fall between the two
+        kernels = [k for k in kernels if "MANY=1" in k]                  #  census snapshots: they are not the region's)
+    elif busy is not None:
+        kernels = [k for k in kernels if "MANY=0" in k]
     bad = [r for r in results if isinstance(r, int) and r != 0]          # return codes of the bound C-ABI launches
     if bad:
         _capi.check(bad[0])
