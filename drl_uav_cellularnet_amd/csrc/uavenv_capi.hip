@@ -397,17 +397,17 @@ static bool call_is_fast(const KParams &p) {
 // multi-step kernel had quoted numbers and no test).  Key = (family, BT, MODE, PLC, variant, MANY).
 enum { FAM_PACKED = 0, FAM_MULTIPASS = 1 };
 enum { VAR_CHECKED = 0, VAR_FAST = 1, VAR_PIN = 2 };
-constexpr int kCensusSlots = 2 * 4 * 5 * 2 * 3 * 3;
+constexpr int kCensusSlots = 2 * 4 * 5 * 2 * 3 * 5;
 static std::atomic<long long> g_census[kCensusSlots];
 static constexpr int bt_index(int bt) { return bt == 4 ? 0 : bt == 8 ? 1 : bt == 16 ? 2 : 3; }
-static constexpr int census_index(int fam, int bt, int mode, bool plc, int var, int many) {   // many: 0 single step, 1 multi-step, 2 multi-step with packed output records
-    return ((((fam * 4 + bt_index(bt)) * 5 + mode) * 2 + (plc ? 1 : 0)) * 3 + var) * 3 + many;
+static constexpr int census_index(int fam, int bt, int mode, bool plc, int var, int many) {   // many: 0 single step, 1 multi-step, 2 multi-step with packed output
+    return ((((fam * 4 + bt_index(bt)) * 5 + mode) * 2 + (plc ? 1 : 0)) * 3 + var) * 5 + many;  // records, 3 / 4 = 1 / 2 under a rotation schedule (SCHED kernels)
 }
 // The image of launch_env's selection logic (keep the two in step: census_count() refuses a key this predicate rejects).
 static bool variant_selectable(int fam, int bt, int mode, bool plc, int var, int many) {
     if (mode == MODE_WARMUP)                               // mobility only: one BT = 4, PLC instantiation per family, FAST or checked
         return bt == 4 && plc && many == 0 && (var == VAR_CHECKED || var == VAR_FAST);
-    if (fam == FAM_PACKED) return many == 0 || mode == MODE_STEP;      // every (BT, PLC, variant); MANY / PKO exist for MODE_STEP only
+    if (fam == FAM_PACKED) return many == 0 || mode == MODE_STEP;      // every (BT, PLC, variant); MANY / PKO / SCHED exist for MODE_STEP only
     if (many != 0 || var == VAR_PIN) return false;              // multi-pass: no PIN variant, uavenv_step_many loops over single steps
     return var == VAR_FAST || bt == 4;                     // the checked multi-pass kernel reads B at run time: BT = 4 serves all
 }
@@ -417,7 +417,7 @@ static bool census_count(int fam, int bt, int mode, bool plc, int var, int many)
     return true;
 }
 static void census_decode(int i, int &fam, int &bt, int &mode, bool &plc, int &var, int &many) {
-    many = i % 3; i /= 3;
+    many = i % 5; i /= 5;
     var = i % 3; i /= 3;
     plc = i & 1; i >>= 1;
     mode = i % 5; i /= 5;
@@ -432,8 +432,8 @@ extern "C" int uavenv_debug_variant_info(int i, char *name, size_t name_len, int
     static const char *modes[5] = {"WARMUP", "RESET", "STEP", "TRACE", "RESET_TRACE"};
     if (name && name_len) {
         if (fam == FAM_PACKED)
-            std::snprintf(name, name_len, "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d, PKO=%d>", bt, modes[mode], (int)plc,
-                          (int)(var != VAR_CHECKED), (int)(var == VAR_PIN), (int)(many != 0), (int)(many == 2));
+            std::snprintf(name, name_len, "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d, PKO=%d%s>", bt, modes[mode], (int)plc,
+                          (int)(var != VAR_CHECKED), (int)(var == VAR_PIN), (int)(many != 0), (int)(many == 2 || many == 4), many >= 3 ? ", SCHED=1" : "");
         else
             std::snprintf(name, name_len, "env_kernel_multipass<BT=%d, %s, PLC=%d, FAST=%d>%s", bt, modes[mode], (int)plc,
                           (int)(var != VAR_CHECKED), (var == VAR_PIN || many != 0) ? " (no such kernel)" : "");
@@ -498,17 +498,21 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     // only when the env launch drains (rocprofv3 timeline, profiles/r04g_*): ranges run unpinned (90 VGPRs).
     if (n_range > 0) pin = false;
     if (h->force_pin >= 0) pin = fast && (h->force_pin == 1);   // experiments only (read once in uavenv_create)
-#define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
+#define UAVENV_LAUNCH_PKS(BT_, PLC_, SCH_)                                                                       \
     do {                                                                                                         \
         if (MANY && tev0 != nullptr) {   /* (multi-step launches with uavenv_launch_timing on: events on the dispatch itself) */ \
-            if (pin) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);     \
-            else if (fast) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS); \
-            else hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);       \
+            if (pin) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);     \
+            else if (fast) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS); \
+            else hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);       \
         } else                                                                                                   \
-        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);     \
-        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS); \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO>), dim3(grid), blk, 0, s, PK_ARGS);       \
-        counted = census_count(FAM_PACKED, BT_, M, PLC_, pin ? VAR_PIN : (fast ? VAR_FAST : VAR_CHECKED), MANY_); \
+        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);     \
+        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS); \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);       \
+        counted = census_count(FAM_PACKED, BT_, M, PLC_, pin ? VAR_PIN : (fast ? VAR_FAST : VAR_CHECKED), MANY_ + ((SCH_) ? 2 : 0)); \
+    } while (0)
+#define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
+    do {                                                                                                         \
+        if (MANY && p.sched != nullptr) UAVENV_LAUNCH_PKS(BT_, PLC_, MANY); else UAVENV_LAUNCH_PKS(BT_, PLC_, false); \
     } while (0)
 #define UAVENV_LAUNCH(BT_)                                                                                       \
     do {                                                                                                         \
@@ -539,6 +543,7 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     }
 #undef UAVENV_LAUNCH
 #undef UAVENV_LAUNCH_PK
+#undef UAVENV_LAUNCH_PKS
 #undef PK_ARGS
     HIP_TRY(hipGetLastError());
     if (!counted) return fail(UAVENV_E_INVALID, "launch census: no kernel launched, or an instantiation outside variant_selectable()");

@@ -1077,12 +1077,16 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
 }
 
 // PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false>
+// SCHED (MANY only): the launch runs a rotation schedule (p.sched).  A kernel of its own, not a branch of the plain multi-step kernel: with
+// the schedule's three body copies inside it the plain unpinned kernel went from 167 to 169-180 VGPRs, i.e. from three to two wavefronts
+// per SIMD, and a 65 536-env call from 46.7 to 52.5 us per step (same-box A/B against the round-3 tree, profiles/r04s_*).
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false, bool SCHED = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
                                                                               int Gr, int B_rt, int lane_magic, int wave0, int e_lo, int e_hi, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
     static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
+    static_assert(!SCHED || MANY, "rotation schedules exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
     // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
     // pointers) is still being fetched: the cold kernarg fetch (~2000 ticks) no longer precedes the load round trip.
@@ -1098,11 +1102,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         // steps of one env-wavefront: state loaded, nt steps, state stored.
         // (Inlined copies of the body rather than a rolled loop around one: with the rolled loop hipcc allocated 330 VGPRs for the
         // pinned kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
-        const int4 *sched = p.sched;
-        if (sched == nullptr) {
+        if (!SCHED) {
             env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks, e_lo, e_hi);
             return;
         }
+        const int4 *sched = p.sched;
         // One-launch schedule: this wavefront is a SLOT with up to kSchedPieces pieces.  A piece that starts inside a job (SCHED_WAIT)
         // waits until the wavefront that ran the job's first steps has published them; a piece that ends inside a job
         // (SCHED_PUBLISH) publishes.  Publishing pieces come FIRST in their slot and wait for nothing, so every wait ends once its

@@ -137,6 +137,26 @@ def test_every_mode_of_one_instantiation_family_matches_the_oracle(shape, varian
         np.testing.assert_allclose(s[k], orc.s[k], rtol=0, atol=1e-9, err_msg=k)
     for k in ("agg", "deagg", "tick", "bs_xy", "serving", "fifo_depth", "out_bits", "step_n", "ue_xy"):
         np.testing.assert_array_equal(s[k], orc.s[k], err_msg=k)
+    if fam == "packed":
+        # The SCHED kernels (a multi-step call under a rotation schedule) of the same (n_bs bound, path loss, variant): a clone
+        # whose handle plans its 3 env-wavefronts onto 2 slots, against this env's plain multi-step launches -- bit for bit (the plain
+        # launches were compared with the oracle above).
+        import ctypes as C
+
+        monkeypatch.setenv("UAVENV_ROTATE", "1")
+        monkeypatch.setenv("UAVENV_ROTATE_SLOTS", "2")
+        env_r = env.clone()
+        nl = C.c_int(-1)
+        assert env_r._lib.uavenv_debug_rotation_info(env_r._h, 4, C.byref(nl), None) == 0 and nl.value == 1
+        a = torch.as_tensor(actions(4), device=env.device)
+        want, got_r = env.step_many(a), env_r.step_many(a)
+        for k in want:
+            assert torch.equal(got_r[k], want[k]), "scheduled step_many: %s" % k
+        a = torch.as_tensor(actions(4), device=env.device)
+        want, got_r = env.unpack_outputs(env.step_many_packed(a)), env_r.unpack_outputs(env_r.step_many_packed(a))
+        for k in want:
+            assert torch.equal(got_r[k], want[k]), "scheduled step_many_packed: %s" % k
+        assert np.array_equal(env.get_state(), env_r.get_state()) and env_r.device_error() == 0
 
 
 def test_every_selectable_instantiation_was_launched_and_nothing_else():
@@ -145,7 +165,7 @@ def test_every_selectable_instantiation_was_launched_and_nothing_else():
 
     census = _capi.launch_census()
     selectable = [c for c in census if c[1]]
-    assert len(selectable) == 188, len(selectable)      # 144 packed + 40 multi-pass + 4 warm-up (csrc/uavenv_capi.hip: variant_selectable)
+    assert len(selectable) == 236, len(selectable)      # 192 packed (incl. 48 SCHED) + 40 multi-pass + 4 warm-up (csrc/uavenv_capi.hip: variant_selectable)
     never = [name for name, sel, n in census if sel and n == 0]
     assert not never, "instantiations launch_env can select but no test of this module launched:\n  " + "\n  ".join(never)
     stray = [name for name, sel, n in census if not sel and n != 0]

@@ -10,6 +10,8 @@ variants = {"default (pipelined halves, heads alternate)": {"pipeline_halves": T
             "three_launches": {"fused_head": False}}
 if len(sys.argv) > 1:
     variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
+variants["pipelined halves, EAGER launches (no graph)"] = {"pipeline_halves": True, "collect_launch": "eager"}
+variants["unsplit, EAGER launches (no graph)"] = {"pipeline_halves": False, "collect_launch": "eager"}
 for parts in (2, 3, 4):
     for mode in ("alternate", "free", "stagger"):
         if (parts, mode) != (2, "alternate"):
