@@ -59,7 +59,8 @@ def main():
     entries = []
     for rn in runs:
         tag, envs, n_bs, n_ue, many, spc = rn["tag"], rn["envs"], rn["n_bs"], rn["n_ue"], bool(rn["many"]), rn["steps_per_call"]
-        trace_steps, pmc_steps = rn["warmup"] + rn["trace_steps"], rn["warmup"] + rn["pmc_steps"]
+        rep = 1 + rn.get("timed_steps_repeated_for_launch_timing", 0)          # bench.py runs the timed steps of a multi-step form twice
+        trace_steps, pmc_steps = rn["warmup"] + rep * rn["trace_steps"], rn["warmup"] + rep * rn["pmc_steps"]
         c = {}
         for p in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
             for k, v in counters(os.path.join(root, "pmc_%s_%s" % (tag, p))).items():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: kernel traces + PMC passes (separate passes: FETCH_SIZE / WRITE_SIZE / SQ) for every env workload bench.py's roofline block
 # describes, each in the DISPATCH FORM the bench runs it in (prewarm_calls: bench.py's measure_env also runs 3 untimed calls of the same
-# form on a scratch env); writes a manifest (runs.json) with the step counts it used, which
+# form on a scratch env, and repeats the timed steps once with uavenv_launch_timing on); writes a manifest (runs.json) with the step counts it used, which
 # tools/make_traffic_json.py reads (no hard-coded counts there).   usage: r04_pmc.sh <out tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-r04e}
@@ -17,7 +17,7 @@ run() {   # tag, envs, n_bs, n_ue, many(1/0), steps per call, schedule, trace st
   local envv=()
   while [ "$1" != "--" ]; do envv+=("$1"); shift; done; shift
   [ $first -eq 1 ] || echo ',' >> $O/runs.json; first=0
-  echo "{\"tag\": \"$tag\", \"envs\": $envs, \"n_bs\": $nbs, \"n_ue\": $nue, \"many\": $many, \"steps_per_call\": $spc, \"schedule\": \"$sched\", \"warmup\": 100, \"trace_steps\": $ts, \"pmc_steps\": $ps, \"prewarm_calls\": $((many * 3))}" >> $O/runs.json
+  echo "{\"tag\": \"$tag\", \"envs\": $envs, \"n_bs\": $nbs, \"n_ue\": $nue, \"many\": $many, \"steps_per_call\": $spc, \"schedule\": \"$sched\", \"warmup\": 100, \"trace_steps\": $ts, \"pmc_steps\": $ps, \"prewarm_calls\": $((many * 3)), \"timed_steps_repeated_for_launch_timing\": $many}" >> $O/runs.json
   for kv in "${envv[@]}"; do export "$kv"; done
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -- python3 $R/bench.py --steps $ts --warmup 100 $A "$@" > $O/trace_$tag.log 2>&1
   echo "trace $tag rc=$?" | tee -a $O/status.txt
