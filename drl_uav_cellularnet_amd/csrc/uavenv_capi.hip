@@ -33,6 +33,7 @@ struct uavenv {
     char *blob;
     int32_t *bs_init_dev;
     long long *act_pow_dev;
+    uint4 *act_dec_dev;  // [B] split decode of the joint action (KParams::act_dec)
     int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
     int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
     const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
@@ -257,6 +258,30 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     long long pw = 1;
     for (int b = cfg->n_bs - 1; b >= 0; --b) { act_pow[b] = pw; pw *= cfg->n_act; }
     const long long n_joint = pw;  // n_act^B = action_space_dim (mobile_env.py:104)
+    // Split decode (KParams::act_dec): the k_lo least significant digits form `lo`, the others `hi`; usable when the joint action is
+    // exact in a double (n_act^B < 2^52) and both halves fit 32 bits.
+    uint4 act_dec[UAVENV_MAX_BS];
+    std::memset(act_dec, 0, sizeof(act_dec));
+    int act_split = 0;
+    unsigned long long act_P = 1;
+    {
+        const int k_lo = cfg->n_bs / 2, k_hi = cfg->n_bs - k_lo;
+        unsigned long long p_lo = 1, p_hi = 1;
+        for (int i = 0; i < k_lo; ++i) p_lo *= (unsigned long long)cfg->n_act;
+        for (int i = 0; i < k_hi; ++i) p_hi *= (unsigned long long)cfg->n_act;
+        if (n_joint > 0xFFFFFFFFll && n_joint < (1ll << 52) && p_lo <= 0xFFFFFFFFull && p_hi <= 0xFFFFFFFFull && k_lo >= 1) {
+            act_split = 1; act_P = p_lo;
+            for (int b = 0; b < cfg->n_bs; ++b) {
+                const int h = cfg->n_bs - 1 - b;                       // power index of UAV b's digit (most significant first)
+                const int in_hi = h >= k_lo ? 1 : 0;
+                unsigned long long pw32 = 1;
+                for (int i = 0; i < (in_hi ? h - k_lo : h); ++i) pw32 *= (unsigned long long)cfg->n_act;
+                uint32_t magic = 0, shift = 0;
+                if (pw32 >= 2) u32div_gen((uint32_t)pw32, &magic, &shift);
+                act_dec[b] = uint4{(uint32_t)in_hi, magic, shift, (uint32_t)pw32};
+            }
+        }
+    }
     // group of every walker (ue_mobility.py:417-426 g_ref), padded so that idle lanes read in range
     const size_t n_gid = U < 64 ? 64 : U;
     std::string gid(n_gid, '\0');
@@ -276,6 +301,8 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     if ((e = hipMalloc((void **)&h->bs_init_dev, sizeof(int32_t) * 2 * UAVENV_MAX_BS)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc bs_init", e);
     if ((e = hipMalloc((void **)&h->act_pow_dev, sizeof(long long) * UAVENV_MAX_BS)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc act_pow", e);
     if ((e = hipMalloc((void **)&h->gid_dev, n_gid)) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc gid table", e);
+    if ((e = hipMalloc((void **)&h->act_dec_dev, sizeof(act_dec))) != hipSuccess) return bail(UAVENV_E_NOMEM, "hipMalloc act_dec", e);
+    if ((e = hipMemcpy(h->act_dec_dev, act_dec, sizeof(act_dec), hipMemcpyHostToDevice)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemcpy act_dec", e);
     if ((e = hipMemset(h->blob, 0, L.total_bytes)) != hipSuccess) return bail(UAVENV_E_HIP, "hipMemset state", e);
     if ((e = hipMemcpy(h->bs_init_dev, cfg->bs_init_xy, sizeof(int32_t) * 2 * UAVENV_MAX_BS, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(UAVENV_E_HIP, "hipMemcpy bs_init", e);
@@ -323,6 +350,7 @@ extern "C" int uavenv_create(const UavEnvConfig *cfg, int64_t n_envs, int device
     k.env = (EnvRec *)(b + L.env); k.bs_xy = (int32_t *)(b + L.bs_xy); k.out_bits = (unsigned long long *)(b + L.out_bits);
     k.bs_init = h->bs_init_dev;
     k.act_pow = h->act_pow_dev;
+    k.act_dec = h->act_dec_dev; k.act_split = act_split; k.act_P = (uint32_t)act_P; k.act_inv_P = 1.0 / (double)act_P;
     k.gid_of_u = h->gid_dev;
     k.sched_flag = h->sched_flag_dev; k.sched_err = h->err_dev; k.sched_spin_us = h->spin_us;
     u32div_gen((uint32_t)cfg->n_act, &k.div_magic, &k.div_shift);   // exact digit extraction (intdiv.h)
@@ -344,6 +372,7 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     (void)hipFree(h->blob);
     (void)hipFree(h->bs_init_dev);
     (void)hipFree(h->act_pow_dev);
+    if (h->act_dec_dev) (void)hipFree(h->act_dec_dev);
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
     if (h->scratch_out) (void)hipFree(h->scratch_out);

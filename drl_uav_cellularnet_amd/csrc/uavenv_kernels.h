@@ -103,6 +103,13 @@ struct KParams {
     UePos *ue_pos; UeAux *ue_aux; GrpRec *grp; EnvRec *env; int32_t *bs_xy; unsigned long long *out_bits;   // state_layout.h
     const int32_t *bs_init;      // [B,2] device copy of the start cells
     const long long *act_pow;    // [B]   n_act^(B-1-b): joint action -> digit of UAV b (most significant first)
+    // Split decode of a joint action beyond 32 bits (B > 8; config 5: 5^16): a = hi * act_P + lo with both halves below 2^32, one double
+    // multiply + a +-1 correction instead of two emulated 64-bit divisions per UAV lane; then a multiply-shift division per UAV
+    // (act_dec[b] = {half: 1 = hi, magic, shift, power}, intdiv.h).  act_split = 0: the plain 64-bit form (n_act^B >= 2^52, or a half >= 2^32).
+    const uint4 *act_dec;
+    int act_split;
+    uint32_t act_P;
+    double act_inv_P;
     const int8_t *gid_of_u;      // [U]   RPGM group of walker u (from group_size)
     // per-call inputs
     const double *inj_theta, *inj_group, *inj_fading;
@@ -318,8 +325,19 @@ __device__ __forceinline__ double heading_from(const U4 &q0, const U4 &q1, int H
 
 // Digit of UAV b in the joint action: Decimal_to_Base_N (ue_mobility.py:310-336), most significant digit ->
 // UAV 0.  One division per UAV lane, all UAVs in parallel (pw = n_act^(B-1-b)).
-__device__ __forceinline__ int action_digit(const KParams &p, long long a, long long pw) {
+__device__ __forceinline__ int action_digit(const KParams &p, long long a, long long pw, int b) {
     if (p.act32) return (int)(((uint32_t)a / (uint32_t)pw) % (uint32_t)p.n_act);
+    if (p.act_split) {                                   // (0 <= a < n_act^B < 2^52: exact in a double)
+        const double ad = fma((double)(uint32_t)((unsigned long long)a >> 32), 4294967296.0, (double)(uint32_t)a);
+        uint32_t hi = (uint32_t)(ad * p.act_inv_P);                                   // floor(a / P) or one off
+        long long r = a - (long long)((unsigned long long)hi * (unsigned long long)p.act_P);
+        if (r < 0) { hi -= 1u; r += (long long)p.act_P; }
+        else if (r >= (long long)p.act_P) { hi += 1u; r -= (long long)p.act_P; }
+        const uint4 d = p.act_dec[b];
+        const uint32_t x = d.x ? hi : (uint32_t)r;
+        const uint32_t q = (d.w == 1u) ? x : u32div(x, d.y, d.z);
+        return (int)(q - (uint32_t)p.n_act * u32div(q, p.div_magic, p.div_shift));
+    }
     return (int)(((unsigned long long)a / (unsigned long long)pw) % (unsigned long long)p.n_act);
 }
 
@@ -879,7 +897,7 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
                 // cooperative form for B > 8: one UAV per lane, sequential rounds, UAV cells staged in LDS
                 if (is_step(MODE)) {
                     int dig = 0;
-                    if (bown) dig = action_digit(p, act, apw);
+                    if (bown) dig = action_digit(p, act, apw, ul);
                     for (int i = 0; i < B; ++i) {  // sequential: UAV i sees the already-moved UAVs j < i
                         const int xi = __shfl(bx, base + i, 64), yi = __shfl(by, base + i, 64), di = __shfl(dig, base + i, 64);
                         int nx, ny;
@@ -1168,10 +1186,13 @@ __device__ __forceinline__ void fading_pair32(const HotConst &H, const LeanCoef 
     f1 = H.sh_mean + H.sh_sd * (r * sa);
 }
 // Received power of one UAV at one walker: the arithmetic of rx_power()'s inner block (channel.py:220-257).
+// (xs, ys) = the walker's cell in metres, (bxs, bys) = the UAV's: coordinate * gridWidth first, then the difference, exactly as
+// GetDistance does (channel.py:220-226); the UAV's pair comes pre-scaled out of LDS (one cvt + one multiply per UAV and step instead of
+// per (walker, UAV) pair: 4 of the ~300 instructions of a fading iteration)
 template <bool PLC>
-__device__ __forceinline__ double rx_gain(const HotConst &H, const LeanCoef &C, int ix, int iy, int bx, int by, double f) {
-    const double fx = H.gw * (double)(ix - bx);
-    const double fy = H.gw * (double)(iy - by);
+__device__ __forceinline__ double rx_gain(const HotConst &H, const LeanCoef &C, double xs, double ys, double bxs, double bys, double f) {
+    const double fx = xs - bxs;
+    const double fy = ys - bys;
     const double d2 = fx * fx + fy * fy;
     double g;
     if (PLC) {
@@ -1216,7 +1237,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 void env_kernel_multipass(const KParams p) {
     const StatePtrs st = state_from_params(p);
     constexpr bool PRE = FAST && has_mobility(MODE);
-    __shared__ int s_bs[kWavesPerBlock][2 * kMaxBs];
+    __shared__ double s_bs[kWavesPerBlock][2 * kMaxBs];          // UAV cells in metres (cell * gridWidth)
     kernarg_warm<(int)sizeof(KParams)>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1256,7 +1277,7 @@ void env_kernel_multipass(const KParams p) {
     const int n_pass = n_full + (R ? 1 : 0);
     const int IT = (MODE == MODE_WARMUP) ? 0 : tail_items(U, B);        // lanes per tail walker in the item layout, or 0
     const int n_ticks = (MODE == MODE_WARMUP) ? p.n_ticks : 1;
-    int *bs_row = s_bs[wave];
+    double *bs_row = s_bs[wave];
 
     // ---- loads that do not depend on the pass --------------------------------------------------------------------
     const EnvRec erec = st.env[e];
@@ -1278,7 +1299,7 @@ void env_kernel_multipass(const KParams p) {
             else { const int2 q = reinterpret_cast<const int2 *>(st.bs_xy)[e * B + lane]; bx = q.x; by = q.y; }
         }
         if (is_step(MODE)) {
-            if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane]);
+            if (bown) dig = action_digit(p, p.actions[e], p.act_pow[lane], lane);
             for (int i = 0; i < B; ++i) {
                 const int xi = __shfl(bx, i, 64), yi = __shfl(by, i, 64), di = __shfl(dig, i, 64);
                 int nx, ny;
@@ -1291,7 +1312,7 @@ void env_kernel_multipass(const KParams p) {
         }
         if (bown) {
             reinterpret_cast<int2 *>(st.bs_xy)[e * B + lane] = int2{bx, by};
-            bs_row[2 * lane] = bx; bs_row[2 * lane + 1] = by;
+            bs_row[2 * lane] = (double)bx * H.gw; bs_row[2 * lane + 1] = (double)by * H.gw;
             if (UAV_OUT(p.out.bs_xy)) reinterpret_cast<int2 *>(p.out.bs_xy)[e * B + lane] = int2{bx, by};
         }
         __builtin_amdgcn_wave_barrier();
@@ -1379,6 +1400,7 @@ void env_kernel_multipass(const KParams p) {
             if (owner && UAV_OUT(p.out.ue_xy)) reinterpret_cast<int *>(pv_oxy)[iu] = (int)(uint16_t)ix | ((int)(uint16_t)iy << 16);
 
             // ---- received powers, best UAV, the two SINR values -------------------------------------------------
+            const double xs = (double)ix * H.gw, ys = (double)iy * H.gw;       // this walker's cell in metres
             int best, serving = aux.serving;
             double bestS, cur = 0.0;
             if (!item) {
@@ -1405,7 +1427,7 @@ void env_kernel_multipass(const KParams p) {
                         if (!PRE || k >= 2) q = philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + k), DOM_FADING);   // (k is wave-uniform)
                         fading_pair(H, C, q, f0, f1);
                     }
-                    const double g0 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
+                    const double g0 = rx_gain<PLC>(H, C, xs, ys, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
                     if (k == 0) { bp = g0; best = 0; all = g0; }
                     else {
                         if (g0 > bp) { others_b = all; bp = g0; best = b0; }
@@ -1415,7 +1437,7 @@ void env_kernel_multipass(const KParams p) {
                     others_s += (b0 == serving) ? 0.0 : g0;
                     ps = (b0 == serving) ? g0 : ps;
                     if (b1 < B) {
-                        const double g1 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b1], bs_row[2 * b1 + 1], f1);
+                        const double g1 = rx_gain<PLC>(H, C, xs, ys, bs_row[2 * b1], bs_row[2 * b1 + 1], f1);
                         if (g1 > bp) { others_b = all; bp = g1; best = b1; }
                         else others_b += g1;
                         all += g1;
@@ -1439,8 +1461,8 @@ void env_kernel_multipass(const KParams p) {
                                  philox_raw(p, (uint32_t)e, tick, (uint32_t)(u * HB + hb), DOM_FADING));
                     fading_pair(H, C, q, f0, f1);
                 }
-                const double g0 = rx_gain<PLC>(H, C, ix, iy, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
-                const double g1 = (b1 < B) ? rx_gain<PLC>(H, C, ix, iy, bs_row[2 * (b1 < B ? b1 : b0)], bs_row[2 * (b1 < B ? b1 : b0) + 1], f1) : 0.0;
+                const double g0 = rx_gain<PLC>(H, C, xs, ys, bs_row[2 * b0], bs_row[2 * b0 + 1], f0);
+                const double g1 = (b1 < B) ? rx_gain<PLC>(H, C, xs, ys, bs_row[2 * (b1 < B ? b1 : b0)], bs_row[2 * (b1 < B ? b1 : b0) + 1], f1) : 0.0;
                 double bp = g0; best = b0;
                 if (b1 < B && g1 > g0) { bp = g1; best = b1; }             // first maximum inside the pair, then across the group
                 group_argmax(bp, best, IT);
