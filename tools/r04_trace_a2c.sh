@@ -1,17 +1,18 @@
 #!/bin/bash
+# rocprofv3 kernel trace of a few A2C iterations at BASELINE config 3 and a steady-state excerpt of the rollout's timeline
+# (PIPE=1: the rollout as two half-batches on two streams, the default; PIPE=0: unsplit).   usage: r04_trace_a2c.sh <out tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r04g
+O=$R/gpurun_out/${1:-r04h}
 mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
-export PIPE=1
+export PIPE=${PIPE:-1}
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_a2c -- python3 $R/tools/prof_a2c_run.py > $O/trace_a2c.log 2>&1
 echo "trace rc=$?" | tee -a $O/status.txt
 cd $R
 find $O -name "*agent_info.csv" -delete
-python3 - <<'PY'
+OUT=$O python3 - <<'PY'
 import csv,glob,os
-R=os.environ.get("GRAFT_REPO_ROOT",".")
-f=glob.glob(R+"/gpurun_out/r04g/trace_a2c/*/*kernel_trace.csv")[0]
+f=glob.glob(os.environ["OUT"]+"/trace_a2c/*/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
 def short(n):
     for k in ("actor_head","sparse_rows_sum","env_kernel_packed","obs_indices"):
