@@ -503,12 +503,18 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         # (uavenv_launch_timing: hipExtLaunchKernelGGL, the dispatch packet's timestamps) -- live in this process, on the launch stream,
         # but outside the wall-clock region above, which therefore holds nothing but the K steps.
         env.launch_timing(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for f in r.compile(K):
             f()
+        e1.record()
         torch.cuda.synchronize()
         launch_us = env.launch_times_us()
         env.launch_timing(False)
-        gpu_ms = sum(launch_us) * 1e-3                                   # device time of the K steps' launches (tape copies / resets excluded)
+        if launch_us:
+            gpu_ms = sum(launch_us) * 1e-3                               # device time of the K steps' launches (tape copies / resets excluded)
+        else:                                                            # (a multi-pass handle runs a multi-step call as single-step launches:
+            gpu_ms, launch_us = e0.elapsed_time(e1), None                #  no multi-step dispatch to time -- stream events around the repeat)
     per_rank = gather_over_ranks([elapsed, gpu_ms], device=reduce_dev)   # every rank's own clock: a straggler must be visible
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
     sched = None
