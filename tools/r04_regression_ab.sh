@@ -1,6 +1,9 @@
 #!/bin/bash
 # same-box A/B of the paths round 4 did NOT mean to change: the round-3 tree (ab_build/r03tree, its own bench.py and libraries) against
 # this tree, alternated: 65 536 envs (unpinned multi-step kernel, plain launch), one kernel per step at 4096 / 8192 envs, config 5
+# Set-up in the build container (ab_build/ is git-ignored but travels to the GPU box):
+#   mkdir -p ab_build/r03tree && git archive bb80d09 drl_uav_cellularnet_amd include bench.py oracle tools profiles/traffic_current.json | tar -x -C ab_build/r03tree
+#   (cd ab_build/r03tree && python -c "import sys; sys.path.insert(0, '.'); from drl_uav_cellularnet_amd import build as b; b.build(force=True)" && make -C oracle -s -B)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04s
 mkdir -p $O
