@@ -1103,6 +1103,10 @@ __global__ __launch_bounds__(kRsThr, 1) void gemm_rows_resident_kernel(const flo
 // workgroup per CU --, 1 (16 rows, wave = column eighth w) for HALF a batch, so that it still spreads over every CU (A2CRunner(pipeline_halves)):
 // the time of a workgroup is mostly its stream of W2^T + W3^T (672 KB) and does not shrink with the number of workgroups.
 constexpr int kHdH = 200, kHdNP = 640, kHdWaves = 8, kHdThr = kHdWaves * 64;
+#ifdef UAVGEMM_STAMPS
+__device__ unsigned long long *g_head_dbg;   // [workgroups][8 waves][10]: s_memtime stamps of actor_head_kernel (tools/head_stamps.py sets it)
+#endif
+__device__ int g_head_no_stagger;      // A/B switch (UAVAGENT_HEAD_STAGGER=0 sets it to 1 through uavagent_actor_head_f32): every wave issues at the chunk's start
 constexpr int kHdW2Rows = 256, kHdW2Pass = kHdW2Rows * 10 / kHdThr;                              // 2560 float4: 5 passes
 constexpr int kHdW3Rows = 320;                                                                  // (rows of a phase-1 ring stage: 256 used)
 constexpr int kHdStageF = kHdW3Rows * kGlBK;                                                    // 12 800 floats per ring stage (phase 1's two)
@@ -1126,8 +1130,10 @@ __device__ __forceinline__ float wave_max_g(float v) {
 
 // 10 k-steps of one chunk: NCB column blocks of one 16-row block.  pa = this lane's A row at the chunk's first k, pw = its W row of
 // column block 0 in the stage (row stride 40); group g + 1 is read while the first k-step of group g issues (see gemm_rows_glds_kernel).
-template <int NCB>
-__device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int q, f32x4 (&acc)[NCB]) {
+// mid(): called once, between k-steps 4 and 5 -- where waves 4-7 of the head issue the NEXT chunk's LDS-DMA loads (see actor_head_kernel:
+// the stagger)
+template <int NCB, class Mid>
+__device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int q, f32x4 (&acc)[NCB], Mid mid) {
     f32x4 a01[2], w01[2][NCB];
     f32x2 a2, w2[NCB];
     a01[0] = *reinterpret_cast<const f32x4 *>(pa + 4 * q);
@@ -1147,6 +1153,7 @@ __device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int
                 if (cb == 0) a2 = *reinterpret_cast<const f32x2 *>(pa + 32 + 2 * q);
                 w2[cb] = *reinterpret_cast<const f32x2 *>(pw + cb * 16 * kGlBK + 32 + 2 * q);
             }
+            if (ks == 5 && cb == 0) { mid(); __builtin_amdgcn_sched_barrier(0); }
             const float av = (g < 2) ? a01[g < 2 ? g : 0][e] : a2[e & 1];
             const float wv = (g < 2) ? w01[g < 2 ? g : 0][cb][e] : w2[cb][e & 1];
             acc[cb] = MFMA16(av, wv, acc[cb]);
@@ -1170,6 +1177,10 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4, rb = (RB == 2) ? (wave & 1) : 0, qt = (RB == 2) ? (wave >> 1) : wave;   // row block, column group
     const long long m0 = (long long)blockIdx.x * kHdRows;
+    const bool stagger_first = (wave < 4) || g_head_no_stagger;      // (waves w and w + 4 share a SIMD)
+    unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hs3 = 0, hs4 = 0, hs5 = 0, hs6 = 0, hs7 = 0, hs_b = 0, hs_t = 0, hs_wait = 0, hs_first = 0;
+    (void)hs0; (void)hs1; (void)hs2; (void)hs3; (void)hs4; (void)hs5; (void)hs6; (void)hs7; (void)hs_b; (void)hs_t; (void)hs_wait; (void)hs_first;
+    GEMM_STAMP(hs0);
     using set0_t = std::integral_constant<int, 0>;
     using set1_t = std::integral_constant<int, 1>;
     // (every wait below is vmcnt(0), so the waves need not issue the same number of LDS-DMA instructions: passes are cut at whole waves)
@@ -1217,11 +1228,19 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     for (int c = 0; c < NCB1; ++c) acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *pa1 = sH1 + (rb * 16 + r) * kHdH;
     auto chunk2 = [&](auto set_c, int c) {
+        GEMM_STAMP(hs_b);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < 5) issue2(set_c, c + 1);
-        head_chunk<NCB1>(pa1 + c * kGlBK, ring + (c & 1) * kHdStageF + (qt * NCB1 * 16 + r) * kGlBK, q, acc1);
+        GEMM_STAMP(hs_t);
+        hs_wait += hs_t - hs_b;
+        if (c == 0) hs_first = hs_t;
+        // The stagger: after the barrier both waves of a SIMD would issue their 5 LDS-DMA instructions at once (60-185 cycles of issue each,
+        // MI355X_MICROARCH.md) and leave the matrix pipe idle meanwhile; waves 0-3 issue at the start of the chunk, waves 4-7 in its middle
+        // (under their partner's MFMAs and vice versa).  Per wave the order of its loads is unchanged, so the counted waits still hold.
+        if (stagger_first && c + 1 < 5) issue2(set_c, c + 1);
+        head_chunk<NCB1>(pa1 + c * kGlBK, ring + (c & 1) * kHdStageF + (qt * NCB1 * 16 + r) * kGlBK, q, acc1,
+                         [&] { if (!stagger_first && c + 1 < 5) issue2(set_c, c + 1); });
     };
     chunk2(set1_t{}, 0); chunk2(set0_t{}, 1); chunk2(set1_t{}, 2); chunk2(set0_t{}, 3); chunk2(set1_t{}, 4);
     // bias + relu6 -> the h2 tile in LDS (row = m, k-contiguous: the A operand of the policy head)
@@ -1234,7 +1253,9 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             for (int t = 0; t < 4; ++t) sH2[(rb * 16 + 4 * q + t) * kHdH + col] = fminf(fmaxf(acc1[cb][t] + bv, 0.0f), 6.0f);
         }
     }
+    GEMM_STAMP(hs1);                                   // phase 1's MFMAs done, h2 written to LDS
     __syncthreads();                                   // (every wave is past the ring's last read too: phase 2 may refill it)
+    GEMM_STAMP(hs2);
 
     // ---- phase 2: logits = h2 @ W3 + b3 in three PARTS of 256 / 256 / 128 policy columns x 5 chunks of 40 k; wave = 16 rows x 4 / 4 / 2 of a
     // part's 16 / 16 / 8 column blocks.  Stages of 256 rows x 40 k (40 KB): three of them fit [h1 tile | ring], so chunk p + 2 is issued when
@@ -1282,24 +1303,30 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     const float *pa2 = sH2 + (rb * 16 + r) * kHdH;
     // chunk p3 has landed once at most the loads of chunk p3 + 1 are outstanding (5 per wave; in part 2: 3 for waves 0-3, 2 for the others)
     auto land3 = [&](int p3) {
+        GEMM_STAMP(hs_b);
         if (p3 + 1 >= 15) wait_vmcnt<0>();
         else if (p3 + 1 < 10) wait_vmcnt<kHdP3Pass>();
         else if (wave < 4) wait_vmcnt<3>();
         else wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(hs_t);
+        hs_wait += hs_t - hs_b;
+        if (p3 == 0) hs3 = hs_t;                       // phase 2's first chunk has landed (h2 store + two chunk issues lie before)
     };
     auto chunk3 = [&](auto set_c, auto ncb_c, int p3, f32x4 (&acc)[decltype(ncb_c)::value]) {       // SET = parity of p3: chunk p3 + 2 is issued here
         constexpr int NCB = decltype(ncb_c)::value;
         land3(p3);
-        if (p3 + 2 < 15) issue3(set_c, p3 + 2);       // its stage was read last in chunk p3 - 1: every wave is past that
-        head_chunk<NCB>(pa2 + (p3 % 5) * kGlBK, ring3 + (p3 % 3) * kHdP3StageF + (qt * NCB * 16 + r) * kGlBK, q, acc);
+        if (stagger_first && p3 + 2 < 15) issue3(set_c, p3 + 2);       // its stage was read last in chunk p3 - 1: every wave is past that
+        head_chunk<NCB>(pa2 + (p3 % 5) * kGlBK, ring3 + (p3 % 3) * kHdP3StageF + (qt * NCB * 16 + r) * kGlBK, q, acc,
+                        [&] { if (!stagger_first && p3 + 2 < 15) issue3(set_c, p3 + 2); });
     };
     using n4_t = std::integral_constant<int, NCB1>;      // column blocks of a wave in parts A and B ...
     using n2_t = std::integral_constant<int, NCBC>;      // ... and in part C
     chunk3(set0_t{}, n4_t{}, 0, accA); chunk3(set1_t{}, n4_t{}, 1, accA); chunk3(set0_t{}, n4_t{}, 2, accA); chunk3(set1_t{}, n4_t{}, 3, accA); chunk3(set0_t{}, n4_t{}, 4, accA);
     chunk3(set1_t{}, n4_t{}, 5, accB); chunk3(set0_t{}, n4_t{}, 6, accB); chunk3(set1_t{}, n4_t{}, 7, accB); chunk3(set0_t{}, n4_t{}, 8, accB); chunk3(set1_t{}, n4_t{}, 9, accB);
     chunk3(set0_t{}, n2_t{}, 10, accC); chunk3(set1_t{}, n2_t{}, 11, accC); chunk3(set0_t{}, n2_t{}, 12, accC); chunk3(set1_t{}, n2_t{}, 13, accC); chunk3(set0_t{}, n2_t{}, 14, accC);
+    GEMM_STAMP(hs4);                                   // phase 2's MFMAs done
     __syncthreads();                                   // the ring is free: it becomes the [32][640] logits tile
 
     // ---- phase 3: + bias -> logits tile in LDS; coalesced store; one wave samples 4 rows ----
@@ -1322,6 +1349,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         for (int t = 0; t < 4; ++t) sL[(rb * 16 + 4 * q + t) * kHdNP + colC] = accC[cb][t] + bC;
     }
     __syncthreads();
+    GEMM_STAMP(hs5);                                   // logits tile in LDS
     {
         const int rows = (int)(n_rows - m0 < kHdRows ? n_rows - m0 : kHdRows);
 #pragma unroll 5
@@ -1330,6 +1358,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             if (row < rows) *reinterpret_cast<float4 *>(logits + (m0 + row) * ldl + c4 * 4) = *reinterpret_cast<const float4 *>(sL + row * kHdNP + c4 * 4);
         }
     }
+    GEMM_STAMP(hs6);                                   // logits stores issued
     constexpr int PER = 10;                            // sample_actions_kernel<10>: lane l owns columns 10 l .. 10 l + 9
     for (int i = 0; i < kHdRows / kHdWaves; ++i) {
         const int lr = wave * (kHdRows / kHdWaves) + i;
@@ -1349,7 +1378,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int c = lane * PER + k;
-            v[k] = (c < n_act) ? expf(v[k] - mx) : 0.f;
+            v[k] = (c < n_act) ? draw_exp(v[k] - mx) : 0.f;
             loc += v[k];
         }
         float incl = loc;
@@ -1376,7 +1405,21 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         }
         if (lane == 0) action[m] = a;
     }
+#ifdef UAVGEMM_STAMPS
+    GEMM_STAMP(hs7);
+    if (g_head_dbg != nullptr && lane == 0) {
+        unsigned long long *d = g_head_dbg + ((long long)blockIdx.x * kHdWaves + wave) * 10;
+        d[0] = hs0; d[1] = hs_first - hs0; d[2] = hs1 - hs0; d[3] = hs2 - hs0; d[4] = hs3 - hs0; d[5] = hs4 - hs0; d[6] = hs5 - hs0; d[7] = hs6 - hs0; d[8] = hs7 - hs0;
+        d[9] = hs_wait;
+    }
+#endif
 }
+
+#ifdef UAVGEMM_STAMPS
+extern "C" int uavagent_debug_set_head_stamps(void *dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_head_dbg), &dev_ptr, sizeof(void *)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <bool NT, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ W, long long ldw,
@@ -1600,6 +1643,14 @@ extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const 
     if (n_rows == 0) return UAVAGENT_OK;
     // 32-row workgroups while they give every CU one (a whole rollout batch of 8192 rows on 256 CUs); 16-row workgroups for fewer rows (half a
     // batch on its own stream): the time of a workgroup is its weight stream, so fewer, larger workgroups would only leave CUs idle
+    {   // A/B switch of the DMA stagger, read once per process
+        static const int no_stagger = [] { const char *e = getenv("UAVAGENT_HEAD_STAGGER"); return (e && e[0] == '0') ? 1 : 0; }();
+        static bool pushed = false;
+        if (!pushed && no_stagger) {
+            if (hipMemcpyToSymbol(HIP_SYMBOL(g_head_no_stagger), &no_stagger, sizeof(int)) != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head: hipMemcpyToSymbol failed");
+        }
+        pushed = true;
+    }
     const char *force_env = getenv("UAVAGENT_HEAD_RB");          // tests / A-B runs: 1 or 2 forces the tile height (read per call)
     const int force_rb = force_env ? atoi(force_env) : 0;
     const int n_cu = cu_count_of_current_device();

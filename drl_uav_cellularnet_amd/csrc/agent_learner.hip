@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float *__rest
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int c = lane * PER + k;
-        v[k] = (c < A) ? expf(v[k] - mx) : 0.f;       // softmax numerator (tf.nn.softmax, main.py:150)
+        v[k] = (c < A) ? draw_exp(v[k] - mx) : 0.f;   // softmax numerator (tf.nn.softmax, main.py:150)
         loc += v[k];
     }
     float incl = loc;                                   // inclusive scan over lanes
