@@ -1181,6 +1181,14 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hs3 = 0, hs4 = 0, hs5 = 0, hs6 = 0, hs7 = 0, hs_b = 0, hs_t = 0, hs_wait = 0, hs_first = 0;
     (void)hs0; (void)hs1; (void)hs2; (void)hs3; (void)hs4; (void)hs5; (void)hs6; (void)hs7; (void)hs_b; (void)hs_t; (void)hs_wait; (void)hs_first;
     GEMM_STAMP(hs0);
+    // the uniforms of this wave's rows, loaded NOW: read where the draw needs them, each was a global round trip (~2 000 cycles by the stamps)
+    // in the middle of a dependent chain, once per row
+    float u_row[kHdRows / kHdWaves];
+#pragma unroll
+    for (int i = 0; i < kHdRows / kHdWaves; ++i) {
+        const long long m = m0 + wave * (kHdRows / kHdWaves) + i;
+        u_row[i] = uni[m < n_rows ? m : 0];
+    }
     using set0_t = std::integral_constant<int, 0>;
     using set1_t = std::integral_constant<int, 1>;
     // (every wait below is vmcnt(0), so the waves need not issue the same number of LDS-DMA instructions: passes are cut at whole waves)
@@ -1360,6 +1368,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
     }
     GEMM_STAMP(hs6);                                   // logits stores issued
     constexpr int PER = 10;                            // sample_actions_kernel<10>: lane l owns columns 10 l .. 10 l + 9
+#pragma unroll
     for (int i = 0; i < kHdRows / kHdWaves; ++i) {
         const int lr = wave * (kHdRows / kHdWaves) + i;
         const long long m = m0 + lr;
@@ -1388,19 +1397,22 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             if (lane >= off) incl += t;
         }
         const float total = __shfl(incl, 63, 64);
-        const float target = uni[m] * total;
+        const float target = u_row[i] * total;
         const unsigned long long over = __ballot(incl > target);
         int a = n_act - 1;
         if (over != 0ull) {
+            // every lane walks its OWN PER values from its own exclusive prefix; the walk of the lane that holds the crossing is the answer
+            // (the same sums in the same order as walking that lane's values by broadcast, without ten dependent cross-lane reads)
             const int first = __ffsll((long long)over) - 1;
-            float c = __shfl(incl - loc, first, 64);
-            int found = -1;
+            float c = incl - loc;
+            int fk = -1;
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                c += __shfl(v[k], first, 64);
-                if (found < 0 && c > target) found = first * PER + k;
+                c += v[k];
+                if (fk < 0 && c > target) fk = k;
             }
-            a = found < 0 ? first * PER + PER - 1 : found;
+            fk = __shfl(fk, first, 64);
+            a = fk < 0 ? first * PER + PER - 1 : first * PER + fk;
             if (a > n_act - 1) a = n_act - 1;
         }
         if (lane == 0) action[m] = a;

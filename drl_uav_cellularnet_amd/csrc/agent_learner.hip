@@ -108,15 +108,17 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float *__rest
     int a = A - 1;                                      // u * total rounding up to total: the last action (the reference clamps too)
     if (over != 0ull) {
         const int first = __ffsll((long long)over) - 1;
-        float c = __shfl(incl - loc, first, 64);        // exclusive prefix of the lane that holds the crossing
-        int found = -1;
-        // every lane walks the PER values of lane `first` (broadcast), all lanes agree
+        // every lane walks its OWN PER values from its own exclusive prefix; the walk of the lane that holds the crossing is the answer
+        // (the same sums in the same order as walking that lane's values by broadcast, without PER dependent cross-lane reads)
+        float c = incl - loc;
+        int fk = -1;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            c += __shfl(v[k], first, 64);
-            if (found < 0 && c > target) found = first * PER + k;
+            c += v[k];
+            if (fk < 0 && c > target) fk = k;
         }
-        a = found < 0 ? first * PER + PER - 1 : found;
+        fk = __shfl(fk, first, 64);
+        a = fk < 0 ? first * PER + PER - 1 : first * PER + fk;
         if (a > A - 1) a = A - 1;
     }
     if (lane == 0) action[r] = a;
