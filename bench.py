@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/s of the HIP hot path (BASELINE.json metric), one JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--grid G] [--launch many|manypk|seq|graph|eager] [--mode env|a2c]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--grid G] [--launch many|seq|graph|eager] [--mode env|a2c]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one batched MobiEnvironment.step() over all envs of a rank (mobile_env.py:150-194).
@@ -17,8 +17,6 @@ ranks (one process per GPU, spawned before anything touches the GPU) and fails l
                    between them (the benchmark's actions are resident in HBM and do not depend on observations, which is the
                    case this entry point exists for).  A 4096-env single-step kernel lasts 8 us whatever launches it, 5.8 us of it
                    outside its arithmetic (kernarg fetch, state load round trip, store drain: DESIGN.md section 4).
-            manypk uavenv_step_many_packed: the same launch with one 12-byte record per walker and one 16-byte record per env and
-                   step instead of nine arrays (3 stores per step instead of 12)
             seq    uavenv_step_seq: one kernel per step, the launches of <= 100 steps issued by ONE C call
             graph  hipGraph replay of chunks of <= 100 captured uavenv_step launches (same steady state; a replay costs 10-20 us
                    of host latency before the first kernel, which a 20-step run feels)
@@ -228,7 +226,7 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU (default 4096; 8192 with --mode a2c)")
     ap.add_argument("--mode", choices=("env", "a2c"), default="env")
-    ap.add_argument("--launch", choices=("many", "manypk", "seq", "graph", "eager"), default="many")
+    ap.add_argument("--launch", choices=("many", "seq", "graph", "eager"), default="many")
     ap.add_argument("--chunk", type=int, default=CHUNK, help="steps per uavenv_step_many launch / per captured graph (default 100; profiling "
                     "runs use 20 to repeat the launch shape of the driver's --steps 20 call)")
     ap.add_argument("--grid", type=int, default=GRID, help="grid cells per side (100 = every reference script; 200 = the class default, "
@@ -297,7 +295,6 @@ class EnvRun:
         self.tape = torch.empty((self.chunk, env.n_envs), dtype=torch.int64, device=env.device)
         self.graphs = {}
         self.many_out = {}
-        self.pk_out = {}
         self.max_step = int(env.cfg.max_step)
         self.t = 0            # steps since the last reset (the constructor's reset counts as one)
         self.cursor = 0       # next pool row
@@ -307,19 +304,13 @@ class EnvRun:
         import torch
 
         for n in sorted(set(sizes)):
-            if self.launch in ("many", "manypk"):
+            if self.launch == "many":
                 self.env.prepare_step_many(n)      # (the launch schedule of this segment length: built here, not inside the timed call)
             if self.launch == "graph" and n not in self.graphs:
                 self.graphs[n] = self.env.capture_steps(self.tape[:n])
             if self.launch == "many" and n not in self.many_out:
                 self.many_out[n] = {k: torch.empty((n,) + tuple(v.shape), dtype=v.dtype, device=v.device)
                                     for k, v in self.env.out.items()}
-            if self.launch == "manypk" and n not in self.pk_out:
-                e = self.env
-                self.pk_out[n] = {"walker": torch.empty((n, e.n_envs, e.nUE, 12), dtype=torch.uint8, device=e.device),
-                                  "bs_xy": torch.empty((n, e.n_envs, e.nBS, 2), dtype=torch.int32, device=e.device),
-                                  "env": torch.empty((n, e.n_envs, 16), dtype=torch.uint8, device=e.device)}
-
     def plan(self, n_steps, t0=None):
         """Segment lengths for n_steps more steps, cut at reset boundaries: [(n, reset_after)]."""
         t = self.t if t0 is None else t0
@@ -372,10 +363,6 @@ class EnvRun:
                 st = env.out_struct_for(self.many_out[n])
                 self._keep_structs = getattr(self, "_keep_structs", []) + [st]
                 prog.append(functools.partial(env._lib.uavenv_step_many, env._h, self.tape.data_ptr(), n, C.byref(st), stream))
-            elif self.launch == "manypk":
-                st = env.packed_out_struct(self.pk_out[n])
-                self._keep_structs = getattr(self, "_keep_structs", []) + [st]
-                prog.append(functools.partial(env._lib.uavenv_step_many_packed, env._h, self.tape.data_ptr(), n, C.byref(st), stream))
             else:
                 prog.extend(functools.partial(env.step, self.tape[t]) for t in range(n))
             self.t += n
@@ -397,8 +384,6 @@ class EnvRun:
                 env.step_seq(self.tape[:n])
             elif self.launch == "many":
                 env.step_many(self.tape[:n], out=self.many_out[n], refresh_out=False)
-            elif self.launch == "manypk":
-                env.step_many_packed(self.tape[:n], out=self.pk_out[n])
             else:
                 for t in range(n):
                     env.step(self.tape[t])
@@ -460,7 +445,7 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         # the clock ramp.  PREWARM_STEPS eager steps, untimed, immediately before the measured env's own W warm-up steps.
         for t in range(PREWARM_STEPS):
             scratch.step(pool[t % n_pool])
-        if launch in ("many", "manypk"):
+        if launch == "many":
             # ... and the scratch env through the SAME launch form and call sizes as the measured one: a multi-step call of another size
             # may take another code path of the kernel (a rotation schedule's pieces, section 4d), and the first execution of a path pays
             # its instruction fetch from memory -- 20-30 us, which a 20-step timed region (0.1 ms) would otherwise carry
@@ -487,7 +472,7 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
         def busy():                              # ~0.5 ms of single steps on the scratch env (the measured env is not touched)
             for t in range(64):
                 scratch.step(pool[t % n_pool])
-    many = launch in ("many", "manypk")
+    many = launch == "many"
     elapsed, gpu_ms = timed(go, dist, dev, keep_busy=busy, events=not many)
     kernels = launched_kernels(census0, _capi.launch_census())          # the instantiation(s) the timed region really launched
     if many:                                                             # (the keep-busy single steps on the scratch env fall between the two
@@ -518,7 +503,7 @@ def measure_env(args, env, launch, K, W, dist, dev, reduce_dev, rank, scratch=No
     per_rank = gather_over_ranks([elapsed, gpu_ms], device=reduce_dev)   # every rank's own clock: a straggler must be visible
     elapsed, gpu_ms = max_over_ranks([elapsed, gpu_ms], device=reduce_dev)          # slowest rank
     sched = None
-    if launch in ("many", "manypk"):                                       # how the library runs a call of this many steps on this handle
+    if launch == "many":                                                   # how the library runs a call of this many steps on this handle
         import ctypes as C
 
         nl, sl = C.c_int(0), C.c_longlong(0)
@@ -768,7 +753,7 @@ def main(argv=None):
     # comes after.  Every measurement has its own env, its own W warm-up steps and its own bracketed timed region.
     alt, grids = {}, {}
     if not args.no_alt:                                # secondary: the other launch forms on the same box, same K / W
-        for other in (("eager", "many", "manypk", "graph", "seq") if world == 1 else ("seq",)):   # N > 1: the one-kernel-per-step form only
+        for other in (("eager", "many", "graph", "seq") if world == 1 else ("seq",)):   # N > 1: the one-kernel-per-step form only
             if other != args.launch:
                 el, gm, info = measure_env(args, make_env(), other, K, W, dist, dev, reduce_dev, rank)
                 alt[other] = {"value": whole_job_rate(E * K, world, el), "unit": "env-steps/s", "us_per_step_wall": el / K * 1e6,
@@ -790,7 +775,7 @@ def main(argv=None):
         per_step_s = gpu_ms * 1e-3 / K   # average per-step device time (HIP events on the launch stream around the timed region)
         b_step = algorithmic_bytes_per_env_step(n_ue, n_bs, len(groups))
         achieved = b_step * E / per_step_s / 1e9
-        many = args.launch in ("many", "manypk")
+        many = args.launch == "many"
         kernel = (info["kernels"] or ["?"])[0]                  # the instantiation the timed region launched (library's launch census)
         spl = min(int(args.chunk), K) if many else 1            # steps one CALL of the step entry point processes
         schedule = (info.get("schedule") or {}).get("form", "plain") if many else "plain"
@@ -840,9 +825,7 @@ def main(argv=None):
                 "graph": "one kernel per step, hipGraph replay of <=100-step chunks",
                 "eager": "one kernel launch per step from Python",
                 "many": "OPEN-LOOP action tape through uavenv_step_many: <=100 consecutive steps per launch, state carried in registers between "
-                        "them, all nine outputs of every step written (a policy in the loop gets single_step_launch_value)",
-                "manypk": "OPEN-LOOP action tape through uavenv_step_many_packed: as `many`, outputs of every step written as packed "
-                          "records (12 B per walker, 8 B per UAV, 16 B per env)"}[args.launch]
+                        "them, all nine outputs of every step written (a policy in the loop gets single_step_launch_value)"}[args.launch]
         line = {
             "metric": "env steps/sec (whole node) at 4-UAV x 20-UE", "value": whole_job_rate(E * K, world, elapsed),
             "unit": "env-steps/s", "n_gpus": n_ranks, "steps": K, "warmup": W,

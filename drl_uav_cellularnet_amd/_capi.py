@@ -42,13 +42,7 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
-class UavEnvOutPacked(C.Structure):
-    _fields_ = [(n, _P) for n in ("walker_dev", "bs_xy_dev", "env_dev")]
-
-
-WALKER_OUT_BYTES, STEP_OUT_BYTES = 12, 16   # sizeof(UavEnvWalkerOut), sizeof(UavEnvStepOut)
-
-ABI_VERSION = 5   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
+ABI_VERSION = 6   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
 STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
@@ -57,7 +51,7 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_step_many", "uavenv_step_many_packed", "uavenv_unpack_outputs", "uavenv_step_seq", "uavenv_step_trace",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area", "uavenv_sinr_area_at",
            "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset", "uavenv_debug_rotation_info", "uavenv_step_many_prepare", "uavenv_device_error", "uavenv_launch_timing", "uavenv_launch_times_us",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
@@ -100,8 +94,6 @@ def load():
     lib.uavenv_step_range.argtypes = [_P, _P, C.c_int64, C.c_int64, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_seq.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
-    lib.uavenv_step_many_packed.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOutPacked), _P]
-    lib.uavenv_unpack_outputs.argtypes = [_P, C.POINTER(UavEnvOutPacked), C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_obs_dense.argtypes = [_P, _P, _P]
     lib.uavenv_obs_dense_update.argtypes = [_P, _P, _P]

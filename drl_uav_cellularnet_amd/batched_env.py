@@ -295,7 +295,7 @@ class BatchedMobiEnv:
         _capi.check(self._lib.uavenv_launch_timing(self._h, 1 if enable else 0))
 
     def launch_times_us(self):
-        """Durations (us) of the step_many / step_many_packed launches since launch_timing(True), in issue order (waits for them)."""
+        """Durations (us) of the step_many launches since launch_timing(True), in issue order (waits for them)."""
         buf = (C.c_double * 256)()
         n = C.c_int(0)
         _capi.check(self._lib.uavenv_launch_times_us(self._h, buf, 256, C.byref(n)))
@@ -335,58 +335,10 @@ class BatchedMobiEnv:
                 v.copy_(out[k][T - 1])
         return out
 
-    # Record formats of the packed outputs (include/uavenv.h: UavEnvWalkerOut, UavEnvStepOut), for host-side decoding.
-    WALKER_OUT_DTYPE = np.dtype([("ix", "<i2"), ("iy", "<i2"), ("cur_sinr", "<f4"), ("serving", "i1"), ("pad", "i1", (3,))])
-    STEP_OUT_DTYPE = np.dtype([("reward", "<f4"), ("mean_sinr", "<f4"), ("step_n", "<i4"), ("n_out", "<i2"), ("done", "u1"), ("pad", "u1")])
-
-    def packed_out_struct(self, packed):
-        st = _capi.UavEnvOutPacked()
-        st.walker_dev, st.bs_xy_dev, st.env_dev = packed["walker"].data_ptr(), packed["bs_xy"].data_ptr(), packed["env"].data_ptr()
-        return st
-
     def prepare_step_many(self, n_steps):
-        """Build whatever a step_many / step_many_packed call of ``n_steps`` steps needs ahead of time (the launch schedule of the
+        """Build whatever a step_many call of ``n_steps`` steps needs ahead of time (the launch schedule of the
         4096-env batch, uavenv_step_many_prepare): the first call with a new n_steps would otherwise build it, synchronously."""
         _capi.check(self._lib.uavenv_step_many_prepare(self._h, int(n_steps)))
-
-    def step_many_packed(self, actions, out=None):
-        """step_many with one RECORD per walker / env and step instead of nine arrays (uavenv_step_many_packed): returns
-        {"walker": uint8 [T, N, U, 12], "bs_xy": int32 [T, N, B, 2], "env": uint8 [T, N, 16]} (record layouts: WALKER_OUT_DTYPE,
-        STEP_OUT_DTYPE); ``unpack_outputs`` turns it into the nine [T, ...] arrays step_many returns, bit for bit.  The multi-step
-        kernel then advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.  ``self.out`` is NOT
-        refreshed (call unpack_outputs / step() before reading it)."""
-        a = actions
-        if not (isinstance(a, torch.Tensor) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()):
-            a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int64).contiguous()
-            self._act_keep = a
-        if a.dim() != 2 or a.shape[1] != self.n_envs:
-            raise ValueError("actions must be [T, n_envs]")
-        T, N, U, B = int(a.shape[0]), self.n_envs, self.nUE, self.nBS
-        shapes = {"walker": ((T, N, U, _capi.WALKER_OUT_BYTES), torch.uint8), "bs_xy": ((T, N, B, 2), torch.int32),
-                  "env": ((T, N, _capi.STEP_OUT_BYTES), torch.uint8)}
-        if out is None:
-            out = {k: torch.empty(sh, dtype=dt, device=self.device) for k, (sh, dt) in shapes.items()}
-        elif set(out) != set(shapes) or any(tuple(out[k].shape) != sh or out[k].dtype != dt or not out[k].is_contiguous()
-                                            for k, (sh, dt) in shapes.items()):
-            raise ValueError("out must be a dict returned by step_many_packed for the same number of steps")
-        st = self.packed_out_struct(out)
-        rc = self._lib.uavenv_step_many_packed(self._h, a.data_ptr(), T, C.byref(st), self._stream())
-        if rc:
-            _capi.check(rc)
-        return out
-
-    def unpack_outputs(self, packed, out=None):
-        """Packed records of T steps -> the nine output arrays, [T, ...] each (uavenv_unpack_outputs)."""
-        T = int(packed["env"].shape[0])
-        if out is None:
-            out = {k: torch.empty((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) for k, v in self.out.items()
-                   if not k.endswith("_f64")}
-        st_in = self.packed_out_struct(packed)
-        st = _capi.UavEnvOut()
-        for k, v in out.items():
-            setattr(st, k + "_dev", v.data_ptr())
-        _capi.check(self._lib.uavenv_unpack_outputs(self._h, C.byref(st_in), T, C.byref(st), self._stream()))
-        return out
 
     def step_trace(self, actions, ue_xy, fading=None):
         """MobiEnvironment.step_test with mobility_model == 'read_trace' (mobile_env.py:196-233)."""

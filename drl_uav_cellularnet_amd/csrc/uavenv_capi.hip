@@ -50,7 +50,6 @@ struct uavenv {
     // the dispatch packet, no marker packets around it), a ring of kTimedLaunches pairs
     std::vector<hipEvent_t> *tev;
     int timing, n_timed;
-    char *scratch_out;  // multi-pass handles, uavenv_step_many_packed: one step's nine output arrays (allocated on first use)
     int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
     UavEnvStateLayout lay;
     KParams kp;  // constants + state pointers, per-call fields patched at launch
@@ -375,7 +374,6 @@ extern "C" void uavenv_destroy(uavenv_t *h) {
     if (h->act_dec_dev) (void)hipFree(h->act_dec_dev);
     (void)hipFree(h->gid_dev);
     if (h->obs_prev_dev) (void)hipFree(h->obs_prev_dev);
-    if (h->scratch_out) (void)hipFree(h->scratch_out);
     if (h->tev) { for (hipEvent_t e : *h->tev) (void)hipEventDestroy(e); delete h->tev; }
     if (h->sched_flag_dev) (void)hipFree(h->sched_flag_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
@@ -426,17 +424,17 @@ static bool call_is_fast(const KParams &p) {
 // multi-step kernel had quoted numbers and no test).  Key = (family, BT, MODE, PLC, variant, MANY).
 enum { FAM_PACKED = 0, FAM_MULTIPASS = 1 };
 enum { VAR_CHECKED = 0, VAR_FAST = 1, VAR_PIN = 2 };
-constexpr int kCensusSlots = 2 * 4 * 5 * 2 * 3 * 5;
+constexpr int kCensusSlots = 2 * 4 * 5 * 2 * 3 * 3;
 static std::atomic<long long> g_census[kCensusSlots];
 static constexpr int bt_index(int bt) { return bt == 4 ? 0 : bt == 8 ? 1 : bt == 16 ? 2 : 3; }
-static constexpr int census_index(int fam, int bt, int mode, bool plc, int var, int many) {   // many: 0 single step, 1 multi-step, 2 multi-step with packed output
-    return ((((fam * 4 + bt_index(bt)) * 5 + mode) * 2 + (plc ? 1 : 0)) * 3 + var) * 5 + many;  // records, 3 / 4 = 1 / 2 under a rotation schedule (SCHED kernels)
+static constexpr int census_index(int fam, int bt, int mode, bool plc, int var, int many) {   // many: 0 single step, 1 multi-step, 2 multi-step under a rotation
+    return ((((fam * 4 + bt_index(bt)) * 5 + mode) * 2 + (plc ? 1 : 0)) * 3 + var) * 3 + many;  // schedule (SCHED kernels)
 }
 // The image of launch_env's selection logic (keep the two in step: census_count() refuses a key this predicate rejects).
 static bool variant_selectable(int fam, int bt, int mode, bool plc, int var, int many) {
     if (mode == MODE_WARMUP)                               // mobility only: one BT = 4, PLC instantiation per family, FAST or checked
         return bt == 4 && plc && many == 0 && (var == VAR_CHECKED || var == VAR_FAST);
-    if (fam == FAM_PACKED) return many == 0 || mode == MODE_STEP;      // every (BT, PLC, variant); MANY / PKO / SCHED exist for MODE_STEP only
+    if (fam == FAM_PACKED) return many == 0 || mode == MODE_STEP;      // every (BT, PLC, variant); MANY / SCHED exist for MODE_STEP only
     if (many != 0 || var == VAR_PIN) return false;              // multi-pass: no PIN variant, uavenv_step_many loops over single steps
     return var == VAR_FAST || bt == 4;                     // the checked multi-pass kernel reads B at run time: BT = 4 serves all
 }
@@ -446,7 +444,7 @@ static bool census_count(int fam, int bt, int mode, bool plc, int var, int many)
     return true;
 }
 static void census_decode(int i, int &fam, int &bt, int &mode, bool &plc, int &var, int &many) {
-    many = i % 5; i /= 5;
+    many = i % 3; i /= 3;
     var = i % 3; i /= 3;
     plc = i & 1; i >>= 1;
     mode = i % 5; i /= 5;
@@ -461,8 +459,8 @@ extern "C" int uavenv_debug_variant_info(int i, char *name, size_t name_len, int
     static const char *modes[5] = {"WARMUP", "RESET", "STEP", "TRACE", "RESET_TRACE"};
     if (name && name_len) {
         if (fam == FAM_PACKED)
-            std::snprintf(name, name_len, "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d, PKO=%d%s>", bt, modes[mode], (int)plc,
-                          (int)(var != VAR_CHECKED), (int)(var == VAR_PIN), (int)(many != 0), (int)(many == 2 || many == 4), many >= 3 ? ", SCHED=1" : "");
+            std::snprintf(name, name_len, "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d%s>", bt, modes[mode], (int)plc,
+                          (int)(var != VAR_CHECKED), (int)(var == VAR_PIN), (int)(many != 0), many == 2 ? ", SCHED=1" : "");
         else
             std::snprintf(name, name_len, "env_kernel_multipass<BT=%d, %s, PLC=%d, FAST=%d>%s", bt, modes[mode], (int)plc,
                           (int)(var != VAR_CHECKED), (var == VAR_PIN || many != 0) ? " (no such kernel)" : "");
@@ -476,10 +474,10 @@ extern "C" void uavenv_debug_variant_reset(void) {
 }
 
 
-// MANY_: 0 = one step / reset / tick batch per launch, 1 = uavenv_step_many (nine output arrays), 2 = uavenv_step_many_packed
+// MANY_: 0 = one step / reset / tick batch per launch, 1 = uavenv_step_many
 template <int MODE, int MANY_ = 0>
 static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long launch_waves = 0, long long first_env = 0, long long n_range = 0) {
-    constexpr bool MANY = MANY_ != 0, PKO = MANY_ == 2;
+    constexpr bool MANY = MANY_ != 0;
     // one wavefront hosts p.epw env instances (packed) or exactly one (multi-pass); 4 wavefronts per workgroup
     // (n_range > 0: envs [first_env, first_env + n_range) only -- uavenv_step_range has checked that the range starts on a wavefront
     //  boundary and ends on one or at N)
@@ -511,8 +509,8 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
         return UAVENV_OK;
     }
     constexpr int M = (MODE == MODE_WARMUP) ? MODE_STEP : MODE;  // (never instantiates the channel modes for WARMUP)
-    // FAST kernels are compiled for B == BT exactly (PKO: there are no optional outputs to test, the three record arrays are mandatory)
-    const bool fast = (PKO ? true : call_is_fast(p)) && (p.B == h->bt);
+    // FAST kernels are compiled for B == BT exactly
+    const bool fast = call_is_fast(p) && (p.B == h->bt);
     // PIN variant (constants pinned in VGPRs, occupancy 2) only when the launch puts between one and two wavefronts on a SIMD.
     // Sweep on one box, pinned vs unpinned (profiles/r01_v19_pin_sweep.txt): 0.67 waves/SIMD 7.50 vs 7.23 us, 1.0 tie, 1.33
     // 8.67 vs 9.20, 2.0 9.29 vs 9.77, 2.67 12.87 vs 12.08, 4.0 15.87 vs 14.98: two co-resident waves profit from constants that
@@ -530,14 +528,14 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
 #define UAVENV_LAUNCH_PKS(BT_, PLC_, SCH_)                                                                       \
     do {                                                                                                         \
         if (MANY && tev0 != nullptr) {   /* (multi-step launches with uavenv_launch_timing on: events on the dispatch itself) */ \
-            if (pin) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);     \
-            else if (fast) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS); \
-            else hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);       \
+            if (pin) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);     \
+            else if (fast) hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS); \
+            else hipExtLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, SCH_>), dim3(grid), blk, 0, s, tev0, tev1, 0, PK_ARGS);       \
         } else                                                                                                   \
-        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);     \
-        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS); \
-        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, PKO, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);       \
-        counted = census_count(FAM_PACKED, BT_, M, PLC_, pin ? VAR_PIN : (fast ? VAR_FAST : VAR_CHECKED), MANY_ + ((SCH_) ? 2 : 0)); \
+        if (pin) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, true, MANY, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);     \
+        else if (fast) hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, true, false, MANY, SCH_>), dim3(grid), blk, 0, s, PK_ARGS); \
+        else hipLaunchKernelGGL((env_kernel_packed<BT_, M, PLC_, false, false, MANY, SCH_>), dim3(grid), blk, 0, s, PK_ARGS);       \
+        counted = census_count(FAM_PACKED, BT_, M, PLC_, pin ? VAR_PIN : (fast ? VAR_FAST : VAR_CHECKED), MANY_ + ((SCH_) ? 1 : 0)); \
     } while (0)
 #define UAVENV_LAUNCH_PK(BT_, PLC_)                                                                              \
     do {                                                                                                         \
@@ -831,80 +829,6 @@ extern "C" int uavenv_step_seq(uavenv_t *h, const int64_t *actions_dev, int n_st
         p.actions = (const long long *)actions_dev + (long long)t * h->N;   // ~8 us a Python -> ctypes -> launch round trip costs
         if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
     }
-    return UAVENV_OK;
-}
-
-// One step's nine output arrays inside the handle's scratch block (multi-pass handles only), each 256-byte aligned.
-static int scratch_outputs(uavenv_t *h, UavEnvOut *o) {
-    const size_t N = (size_t)h->N, U = (size_t)h->cfg.n_ue, B = (size_t)h->cfg.n_bs;
-    const size_t sizes[9] = {4 * N, N, 4 * N, 4 * N, 4 * N * U, 8 * N * B, N * U, 4 * N * U, 4 * N};
-    size_t off[9], total = 0;
-    for (int i = 0; i < 9; ++i) { off[i] = total; total = align_up(total + sizes[i], 256); }
-    if (!h->scratch_out && hipMalloc((void **)&h->scratch_out, total) != hipSuccess)
-        return fail(UAVENV_E_NOMEM, "step_many_packed: hipMalloc scratch outputs");
-    char *b = h->scratch_out;
-    std::memset(o, 0, sizeof(*o));
-    o->reward_dev = (float *)(b + off[0]); o->done_dev = (uint8_t *)(b + off[1]); o->mean_sinr_dev = (float *)(b + off[2]);
-    o->n_out_dev = (int32_t *)(b + off[3]); o->ue_xy_dev = (int16_t *)(b + off[4]); o->bs_xy_dev = (int32_t *)(b + off[5]);
-    o->serving_dev = (int8_t *)(b + off[6]); o->cur_sinr_dev = (float *)(b + off[7]); o->step_n_dev = (int32_t *)(b + off[8]);
-    return UAVENV_OK;
-}
-
-static OutPacked packed_block(const UavEnvOutPacked &o, long long t, long long N, long long U, long long B) {
-    OutPacked k;
-    k.walker = (WalkerOut *)o.walker_dev + t * N * U;
-    k.bs_xy = (int2 *)o.bs_xy_dev + t * N * B;
-    k.env = (StepOut *)o.env_dev + t * N;
-    return k;
-}
-
-static_assert(sizeof(UavEnvWalkerOut) == sizeof(WalkerOut) && sizeof(UavEnvStepOut) == sizeof(StepOut), "header / kernel records differ");
-
-extern "C" int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOutPacked *out, void *stream) {
-    if (!h || !actions_dev || n_steps < 0 || !out || !out->walker_dev || !out->bs_xy_dev || !out->env_dev)
-        return fail(UAVENV_E_INVALID, "step_many_packed: null handle / actions / output record array, or negative n_steps");
-    if (n_steps == 0) return UAVENV_OK;
-    DeviceGuard guard(h->device);
-    if (int rc_dev = poisoned(h, "step_many_packed")) return rc_dev;
-    const long long N = h->N, U = h->cfg.n_ue, B = h->cfg.n_bs;
-    if (h->packed) {
-        KParams p = h->kp;
-        fill_call(p, nullptr, nullptr);
-        p.pk = packed_block(*out, 0, N, U, B);
-        p.actions = (const long long *)actions_dev; p.n_ticks = n_steps;
-        return launch_many<2>(h, p, n_steps, (hipStream_t)stream);
-    }
-    // multi-pass handles (n_ue > 64): per step one single-step launch into the scratch block, then the packing kernel
-    UavEnvOut so;
-    if (int rc = scratch_outputs(h, &so)) return rc;
-    for (int t = 0; t < n_steps; ++t) {
-        KParams p = h->kp;
-        fill_call(p, nullptr, &so);
-        p.actions = (const long long *)actions_dev + (long long)t * N; p.n_ticks = 1;
-        if (int rc = launch_env<MODE_STEP>(h, p, (hipStream_t)stream)) return rc;
-        const long long total = N * (U + B + 1);
-        hipLaunchKernelGGL((repack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, (int)U, (int)B,
-                           packed_block(*out, t, N, U, B), p.out);
-        HIP_TRY(hipGetLastError());
-    }
-    return UAVENV_OK;
-}
-
-extern "C" int uavenv_unpack_outputs(uavenv_t *h, const UavEnvOutPacked *in, int n_steps, const UavEnvOut *out, void *stream) {
-    if (!h || !in || !out || n_steps < 0 || !in->walker_dev || !in->bs_xy_dev || !in->env_dev)
-        return fail(UAVENV_E_INVALID, "unpack_outputs: null handle / record array / output set, or negative n_steps");
-    if (out->cur_sinr_f64_dev || out->mean_sinr_f64_dev || out->reward_f64_dev)
-        return fail(UAVENV_E_INVALID, "unpack_outputs: the packed records hold float32 values; float64 copies are not available");
-    if (n_steps == 0) return UAVENV_OK;
-    DeviceGuard guard(h->device);
-    const long long N = h->N, U = h->cfg.n_ue, B = h->cfg.n_bs;
-    KParams p = h->kp;
-    fill_call(p, nullptr, out);
-    const long long total = N * n_steps * (U + B + 1);
-    if (total > 0x7FFFFFFFll * 256) return fail(UAVENV_E_INVALID, "unpack_outputs: too many records for one launch");
-    hipLaunchKernelGGL((repack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N * n_steps, (int)U,
-                       (int)B, packed_block(*in, 0, N, U, B), p.out);
-    HIP_TRY(hipGetLastError());
     return UAVENV_OK;
 }
 

@@ -77,16 +77,6 @@ struct OutPtrs {
     double *cur_sinr_f64, *mean_sinr_f64, *reward_f64;
 };
 
-// Packed per-step output records (include/uavenv.h: UavEnvWalkerOut / UavEnvStepOut / UavEnvOutPacked): what the nine arrays of
-// OutPtrs hold, as one 12-byte record per walker, one int2 per UAV and one 16-byte record per env.  A multi-step launch then
-// advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.
-struct alignas(4) WalkerOut { int16_t ix, iy; float cur_sinr; int8_t serving; int8_t pad0, pad1, pad2; };
-struct alignas(16) StepOut { float reward, mean_sinr; int32_t step_n; uint32_t nout_done; };   // last dword = {i16 n_out; u8 done; u8 pad}, formed
-                                                                                              // in a register so the record is ONE dwordx4 store
-__host__ __device__ constexpr uint32_t step_out_tail(int n_out, int done) { return ((uint32_t)n_out & 0xFFFFu) | ((uint32_t)(done != 0) << 16); }
-static_assert(sizeof(WalkerOut) == 12 && sizeof(StepOut) == 16, "packed output records are part of the ABI");
-struct OutPacked { WalkerOut *walker; int2 *bs_xy; StepOut *env; };   // [T][N][U], [T][N][B], [T][N]
-
 struct KParams {
     // shape / constants
     int U, B, Gr, G, W64, epw, act32;
@@ -116,7 +106,6 @@ struct KParams {
     const long long *actions; const uint8_t *mask; const int16_t *trace_xy; int n_ticks;
     OutPtrs out;
     unsigned long long *dbg;   // diagnostic builds only (UAVENV_STAMPS): [waves][8] s_memtime stamps
-    OutPacked pk;              // uavenv_step_many_packed (PKO kernels): packed output records instead of `out`
     const int4 *sched;         // multi-step launches: work descriptors [launch waves][kSchedPieces] {env-wavefront, first step, steps,
                                // SCHED_* bits} of a rotation schedule (uavenv_capi.hip: rotation_plan), or null = wave w runs
                                // env-wavefront w, all steps
@@ -692,18 +681,6 @@ __device__ __forceinline__ void out_skip_steps(OutPtrs &o, long long t0, long lo
     if (UAV_OUT64(o.reward_f64)) o.reward_f64 += n;
 }
 
-// One step's per-env outputs as ONE 16-byte record (PKO kernels): the arithmetic of env_finish's step branch
-// (mobile_env.py:163-189; channel.py:216), `step_n` = the count BEFORE this step.
-__device__ __forceinline__ void env_finish_packed(const KParams &p, StepOut *dst, uint32_t e, int step_n, double sum_cur, int n_outage) {
-    const double mean = sum_cur * p.inv_U;
-    const double r0 = sum_cur * p.inv_U20;
-    const double r1 = -((double)n_outage * p.inv_U);
-    double reward = (0.0 + r0) + r1;
-    if (-1.0 > reward) reward = -1.0;
-    step_n += 1;
-    stx(dst, e, StepOut{(float)reward, (float)mean, step_n, step_out_tail(n_outage, step_n >= p.max_step)});
-}
-
 // ================================================================================================
 // state construction: ue_mobility.py:433-451 + mobile_env.py:58-59.  `per` threads per env.
 // ================================================================================================
@@ -766,7 +743,7 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // number of steps (multi-step launches; a plain launch runs env-wavefront = hardware wavefront and all of p.n_ticks).
 // HO (pieces of a one-launch schedule): bit 0 = this piece continues a job another wavefront started (state LOADED coherently),
 // bit 1 = another wavefront continues this piece's job (state STORED coherently); 0 everywhere else.
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, bool PKO, int HO = 0>
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, int HO = 0>
 __device__ __forceinline__ void env_packed_body(char *blob, const long long *actions, const int8_t *gid_of_u, long long N, int U, int EPW,
                                                 int Gr, int B_rt, int lane_magic, const KParams &p, int (*s_bs)[kMaxEpw][2 * kMaxBs],
                                                 const int wave, const long long ew, const int t0, const int nt, const int e_lo, const int e_hi) {
@@ -877,9 +854,7 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
     int n_outage = 0;
     unsigned long long ob = 0ull;
     OutPtrs om = p.out;                                // MANY: the current step's output blocks (dead code otherwise)
-    OutPacked ok = p.pk;                               // PKO: the current step's record blocks
-    if (MANY && !PKO) out_skip_steps<FAST>(om, t0, N, U, B);
-    if (PKO) { ok.walker += (long long)t0 * N * U; ok.bs_xy += (long long)t0 * N * B; ok.env += (long long)t0 * N; }
+    if (MANY) out_skip_steps<FAST>(om, t0, N, U, B);
     for (int it = 0; it < n_ticks; ++it) {
         long long act_next = 0;
         if (MANY) {                                    // prefetch the next step's action: its round trip hides behind this step
@@ -984,19 +959,7 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
             if (!is_reset(MODE)) n_outage = __popcll(ob & ~prev_out);                      // :171-174 newly outaged
             sum_cur = slot_sum(live ? cur : 0.0, ul, U);
         }
-        if (PKO) {
-            // ---- this step's outputs as packed records: three stores, three advancing pointers ---------------------------
-            if (live) stx(ok.walker, iu32, WalkerOut{(int16_t)ix, (int16_t)iy, (float)cur, (int8_t)serving, 0, 0, 0});
-            if (bown) stx(ok.bs_xy, ib32, int2{bx, by});
-            if (head) env_finish_packed(p, ok.env, e32, step_n, sum_cur, n_outage);
-            if (it + 1 < n_ticks) {
-                ok.walker += N * U; ok.bs_xy += N * B; ok.env += N;
-                prev_out = ob;
-                depth = depth < 3 ? depth + 1 : depth;
-                step_n += 1;
-                act = act_next;
-            }
-        } else if (MANY) {
+        if (MANY) {
             // ---- this step's outputs (block `it` of every output array), then the hand-over to the next step ------------
             if (live) {
                 if (UAV_OUT(om.ue_xy)) { stx(om.ue_xy, 2u * iu32, (int16_t)ix); stx(om.ue_xy, 2u * iu32 + 1u, (int16_t)iy); }
@@ -1045,8 +1008,7 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
         const uint32_t ew = block_local<!PIN>(e32);
         if (MODE != MODE_WARMUP) stx_c<STC>(st.out_bits, ew, ob);                                // :116 / :173
         // (MANY: outputs of the LAST step + the record; depth / step_n are the values that step started from)
-        if (PKO) env_finish<MODE, FAST, true, false, STC>(p, p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);   // record only
-        else env_finish<MODE, FAST, true, true, STC>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        env_finish<MODE, FAST, true, true, STC>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)
@@ -1094,16 +1056,14 @@ __device__ __forceinline__ bool sched_hand_off_wait(const KParams &p, int ew) {
     return true;
 }
 
-// PKO (MANY only): outputs go to the packed records of p.pk (uavenv_step_many_packed) instead of the nine arrays of p.out.
 // SCHED (MANY only): the launch runs a rotation schedule (p.sched).  A kernel of its own, not a branch of the plain multi-step kernel: with
 // the schedule's three body copies inside it the plain unpinned kernel went from 167 to 169-180 VGPRs, i.e. from three to two wavefronts
 // per SIMD, and a 65 536-env call from 46.7 to 52.5 us per step (same-box A/B against the round-3 tree, profiles/r04s_*).
-template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool PKO = false, bool SCHED = false>
+template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY = false, bool SCHED = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *blob, const long long *actions,
                                                                               const int8_t *gid_of_u, long long N, int U, int EPW,
                                                                               int Gr, int B_rt, int lane_magic, int wave0, int e_lo, int e_hi, const KParams p) {
     static_assert(!MANY || MODE == MODE_STEP, "multi-step launches exist for MobiEnvironment.step only");
-    static_assert(!PKO || MANY, "packed output records exist for multi-step launches only");
     static_assert(!SCHED || MANY, "rotation schedules exist for multi-step launches only");
     // Leading scalars arrive in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=16), so the global
     // loads of the load phase are issued from them at once while the parameter struct `p` (constants, output
@@ -1113,7 +1073,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
     // this wavefront's env-wavefront (uniform).  wave0 > 0: a launch over a RANGE of the batch (uavenv_step_range: envs wave0 * EPW ...)
     const long long gw = (long long)blockIdx.x * kWavesPerBlock + wave + wave0;
     if (!MANY) {
-        env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1, e_lo, e_hi);
+        env_packed_body<BT, MODE, PLC, FAST, PIN, MANY>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, 1, e_lo, e_hi);
     } else {
         // Multi-step launch.  Plain: wavefront w hosts env-wavefront w for all p.n_ticks steps.  Rotation schedule (p.sched,
         // uavenv_capi.hip: rotation_plan): this wavefront is a SLOT that works through up to three pieces, each a run of consecutive
@@ -1121,7 +1081,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
         // (Inlined copies of the body rather than a rolled loop around one: with the rolled loop hipcc allocated 330 VGPRs for the
         // pinned kernel instead of 233 -- one wavefront per SIMD -- and doubled its SGPR spills.)
         if (!SCHED) {
-            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks, e_lo, e_hi);
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs, wave, gw, 0, p.n_ticks, e_lo, e_hi);
             return;
         }
         const int4 *sched = p.sched;
@@ -1139,7 +1099,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void env_kernel_packed(char *b
             if (nt <= 0) return true;
             if (Q > 0) __builtin_amdgcn_wave_barrier();                       // (the previous piece's reads of the LDS row are done)
             if (Q == 2) { if (!sched_hand_off_wait(p, ew)) return false; }
-            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, PKO, (Q == 0 ? 2 : (Q == 2 ? 1 : 0))>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs,
+            env_packed_body<BT, MODE, PLC, FAST, PIN, MANY, (Q == 0 ? 2 : (Q == 2 ? 1 : 0))>(blob, actions, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p, s_bs,
                                                                                                   wave, ew, t0, nt, e_lo, e_hi);
             if (Q == 0 && (bits & SCHED_PUBLISH)) sched_hand_off_publish(p, ew);
             return true;
@@ -1630,46 +1590,6 @@ __global__ __launch_bounds__(256) void sinr_area_kernel(const KParams p, const i
     const long long o = e * (long long)G * G + (long long)x * G + y;
     if (out32) out32[o] = (float)s;
     if (out64) out64[o] = s;
-}
-
-// ================================================================================================
-// Packed output records <-> the nine output arrays, for n_blocks steps ([T][...] on both sides).  One thread per walker / UAV /
-// env of a step; null members of `o` are skipped.  TO_PACKED = false: uavenv_unpack_outputs; true: the multi-pass handles'
-// uavenv_step_many_packed (their step kernel writes the nine arrays of a scratch block, this kernel packs it).
-// ================================================================================================
-template <bool TO_PACKED>
-__global__ __launch_bounds__(256) void repack_kernel(long long n_env_steps, int U, int B, OutPacked k, OutPtrs o) {
-    const long long per = (long long)U + B + 1;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_env_steps * per) return;
-    const long long e = t / per;                       // (step, env) pair
-    const int r = (int)(t - e * per);
-    if (r < U) {
-        const long long i = e * U + r;
-        if (TO_PACKED) {
-            k.walker[i] = WalkerOut{o.ue_xy[2 * i], o.ue_xy[2 * i + 1], o.cur_sinr[i], o.serving[i], 0, 0, 0};
-        } else {
-            const WalkerOut w = k.walker[i];
-            if (o.ue_xy) { o.ue_xy[2 * i] = w.ix; o.ue_xy[2 * i + 1] = w.iy; }
-            if (o.serving) o.serving[i] = w.serving;
-            if (o.cur_sinr) o.cur_sinr[i] = w.cur_sinr;
-        }
-    } else if (r < U + B) {
-        const long long i = e * B + (r - U);
-        if (TO_PACKED) k.bs_xy[i] = int2{o.bs_xy[2 * i], o.bs_xy[2 * i + 1]};
-        else if (o.bs_xy) { const int2 c = k.bs_xy[i]; o.bs_xy[2 * i] = c.x; o.bs_xy[2 * i + 1] = c.y; }
-    } else {
-        if (TO_PACKED) {
-            k.env[e] = StepOut{o.reward[e], o.mean_sinr[e], o.step_n[e], step_out_tail(o.n_out[e], o.done[e])};
-        } else {
-            const StepOut v = k.env[e];
-            if (o.reward) o.reward[e] = v.reward;
-            if (o.mean_sinr) o.mean_sinr[e] = v.mean_sinr;
-            if (o.step_n) o.step_n[e] = v.step_n;
-            if (o.n_out) o.n_out[e] = (int16_t)(v.nout_done & 0xFFFFu);
-            if (o.done) o.done[e] = (uint8_t)((v.nout_done >> 16) & 1u);
-        }
-    }
 }
 
 }  // namespace uavk

@@ -23,11 +23,13 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 5   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
+#define UAVENV_ABI_VERSION 6   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
                                 * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
                                 *      uavenv_step_many_prepare;
                                 * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs), uavenv_step_range,
-                                *      uavenv_launch_timing / uavenv_launch_times_us */
+                                *      uavenv_launch_timing / uavenv_launch_times_us;
+                                * 6: - uavenv_step_many_packed / uavenv_unpack_outputs (ABI 4's packed output records: no benefit once measured
+                                *      under the one-launch schedule, removed with their 24 kernel instantiations per shape) */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -145,23 +147,6 @@ int uavenv_step_range(uavenv_t *h, const int64_t *actions_dev, int64_t first_env
  * keep stepping with done = 1.  n_ue <= 64: walker / group / UAV state stays in registers across the steps (no per-step launch,
  * state load or state store); n_ue > 64: n_steps single-step launches on `stream`. */
 int uavenv_step_many(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOut *out, void *stream);
-/* uavenv_step_many with the outputs of a step as RECORDS instead of nine arrays: one 12-byte record per walker (what
- * ue_xy / cur_sinr / serving hold), the UAV cells as they are, one 16-byte record per env (reward, mean_sinr, step_n, n_out,
- * done).  Same steps, same values (tests/test_step_many_gpu.py: bit-identical after uavenv_unpack_outputs); the multi-step kernel
- * then advances 3 output pointers instead of 9 and issues 3 stores per step instead of 12.  All three arrays are mandatory:
- * walker_dev [n_steps, N, U], bs_xy_dev [n_steps, N, B, 2], env_dev [n_steps, N].  n_ue > 64: single-step launches + a packing
- * kernel per step (a scratch output block is allocated on the first such call: not inside a captured region). */
-typedef struct UavEnvWalkerOut { int16_t ix, iy; float cur_sinr; int8_t serving; int8_t _pad[3]; } UavEnvWalkerOut;            /* 12 B */
-typedef struct UavEnvStepOut { float reward, mean_sinr; int32_t step_n; int16_t n_out; uint8_t done, _pad; } UavEnvStepOut;   /* 16 B */
-typedef struct UavEnvOutPacked {
-    UavEnvWalkerOut *walker_dev;
-    int32_t *bs_xy_dev;
-    UavEnvStepOut *env_dev;
-} UavEnvOutPacked;
-int uavenv_step_many_packed(uavenv_t *h, const int64_t *actions_dev, int n_steps, const UavEnvOutPacked *out, void *stream);
-/* Records of n_steps steps -> the nine arrays of `out`, [n_steps, ...] each (NULL members are skipped; float64 copies are refused:
- * the records hold float32). */
-int uavenv_unpack_outputs(uavenv_t *h, const UavEnvOutPacked *in, int n_steps, const UavEnvOut *out, void *stream);
 /* The same n_steps steps as n_steps ordinary launches of the single-step kernel issued by ONE host call: step t reads row t of
  * actions_dev [n_steps, N]; `out` is the single-step output set, overwritten by every step (it holds the last step's results
  * afterwards), exactly as n_steps calls of uavenv_step would leave it.  For callers that pay a high price per host call
@@ -212,12 +197,12 @@ int uavenv_debug_variant_count(void);
 int uavenv_debug_variant_info(int i, char *name, size_t name_len, int *selectable, long long *launches);
 void uavenv_debug_variant_reset(void);
 
-/* Optional: prepare a multi-step call of n_steps ahead of time.  The first uavenv_step_many / _packed call with a new n_steps may build and
+/* Optional: prepare a multi-step call of n_steps ahead of time.  The first uavenv_step_many call with a new n_steps may build and
  * upload a launch schedule (a few hundred microseconds of host time, synchronous); a caller that times the call (bench.py) or must not
  * stall in it builds the schedule here instead.  Idempotent; 0 when there is nothing to prepare for this handle / n_steps. */
 int uavenv_step_many_prepare(uavenv_t *h, int n_steps);
 
-/* Test hook: how uavenv_step_many / uavenv_step_many_packed would run n_steps on this handle: *n_launches = 0 for the plain single
+/* Test hook: how uavenv_step_many would run n_steps on this handle: *n_launches = 0 for the plain single
  * launch, else the number of launches of the rotation schedule (1 = the one-launch schedule with hand-offs
  * between wavefronts; the several-launch schedule of ABI 4 is gone) and *slots wavefronts per launch.  Environment, read once in
  * uavenv_create: UAVENV_ROTATE=0 never rotate, =1 rotate whenever a valid schedule exists; UAVENV_ROTATE_SLOTS=k plan as if the
@@ -228,7 +213,7 @@ int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long l
 
 /* Duration of the multi-step launches themselves, for callers that time SHORT calls (bench.py's 20-step region lasts 0.1 ms: a pair of
  * HIP events recorded on the stream around the call are two marker packets that cost it 10 us).  uavenv_launch_timing(h, 1) makes every
- * following uavenv_step_many / _packed dispatch carry its own start / stop events (hipExtLaunchKernelGGL: the dispatch packet's
+ * following uavenv_step_many dispatch carry its own start / stop events (hipExtLaunchKernelGGL: the dispatch packet's
  * timestamps); uavenv_launch_times_us returns the durations of the up-to-256 launches since then in issue order (it waits for them),
  * *n_out = how many were launched.  uavenv_launch_timing(h, 0) switches back to plain launches.  Not capturable. */
 int uavenv_launch_timing(uavenv_t *h, int enable);

@@ -108,7 +108,7 @@ def test_step_many_and_graph_at_bench_sizes_match_the_oracle_on_windows(n, rotat
     pinned = n == 4096 or (n == 8192 and rotate is None)          # resident wavefronts <= 2 per SIMD
     if torch.cuda.get_device_properties(0).multi_processor_count == 256:
         sched = ", SCHED=1" if (rotate is None and n in (4096, 8192)) else ""          # the schedule's own kernel instantiation
-        assert ran == ["env_kernel_packed<BT=4, STEP, PLC=1, FAST=1, PIN=%d, MANY=1, PKO=0%s>" % (1 if pinned else 0, sched)], ran
+        assert ran == ["env_kernel_packed<BT=4, STEP, PLC=1, FAST=1, PIN=%d, MANY=1%s>" % (1 if pinned else 0, sched)], ran
 
 
 @pytest.mark.parametrize("n_envs", [8192])

@@ -22,8 +22,7 @@ F64_KEYS = ("cur_sinr_f64", "mean_sinr_f64", "reward_f64")
 # (family, n_bs, n_ue, n_envs): packed needs n_ue <= 64 and n_ue >= n_bs; 7 envs at 20 UEs = 3 wavefronts, the last one ragged
 SHAPES = [("packed", 4, 20, 7), ("packed", 8, 24, 5), ("packed", 16, 32, 5), ("packed", 32, 64, 3),
           ("multipass", 4, 72, 3), ("multipass", 8, 80, 3), ("multipass", 16, 72, 3), ("multipass", 32, 66, 3),
-          # n_bs below the template bound: the checked kernels with a run-time UAV count -- the only way to the checked variant of
-          # the packed-output multi-step kernel (its three record arrays are mandatory, so no optional-pointer test selects it)
+          # n_bs below the template bound: the checked kernels with a run-time UAV count
           ("packed", 3, 20, 7), ("packed", 6, 24, 5), ("packed", 12, 32, 5), ("packed", 20, 64, 3)]
 G = 40
 
@@ -110,18 +109,12 @@ def test_every_mode_of_one_instantiation_family_matches_the_oracle(shape, varian
     torch.cuda.synchronize()
     for t in range(4):
         _compare({k: v[t].cpu().numpy() for k, v in many.items()}, orc.step(a[t]), "step_many block %d" % t, f64)
-    a = actions(3)                                                               # uavenv_step_many_packed: the PKO kernels (packed) /
-    pk = env.step_many_packed(torch.as_tensor(a, device=env.device))             # single steps + the packing kernel (multi-pass)
-    un = env.unpack_outputs(pk)
-    torch.cuda.synchronize()
-    for t in range(3):
-        _compare({k: v[t].cpu().numpy() for k, v in un.items()}, orc.step(a[t]), "step_many_packed block %d" % t, False)
     mask = (np.arange(N) % 2 == 0).astype(np.uint8)                              # MODE_RESET on a subset
     env.reset(mask=mask)
-    sel = mask.astype(bool)             # (the envs not reset keep stale entries in env.out: step_many_packed does not refresh it)
+    sel = mask.astype(bool)
     _compare({k: v[sel] for k, v in got().items()}, {k: v[sel] for k, v in orc.reset(mask=mask).items()}, "masked reset", f64)
-    a = actions(3)                                                               # passes max_step = 12 on the envs not reset: done = 1
-    for t in range(3):
+    a = actions(6)                                                               # passes max_step = 12 on the envs not reset: done = 1
+    for t in range(6):
         env.step(torch.as_tensor(a[t], device=env.device))
         _compare(got(), orc.step(a[t]), "step after reset %d" % t, f64)
     assert int(env.out["done"].max()) == 1 and int(env.out["done"].min()) == 0
@@ -152,10 +145,6 @@ def test_every_mode_of_one_instantiation_family_matches_the_oracle(shape, varian
         want, got_r = env.step_many(a), env_r.step_many(a)
         for k in want:
             assert torch.equal(got_r[k], want[k]), "scheduled step_many: %s" % k
-        a = torch.as_tensor(actions(4), device=env.device)
-        want, got_r = env.unpack_outputs(env.step_many_packed(a)), env_r.unpack_outputs(env_r.step_many_packed(a))
-        for k in want:
-            assert torch.equal(got_r[k], want[k]), "scheduled step_many_packed: %s" % k
         assert np.array_equal(env.get_state(), env_r.get_state()) and env_r.device_error() == 0
 
 
@@ -165,7 +154,7 @@ def test_every_selectable_instantiation_was_launched_and_nothing_else():
 
     census = _capi.launch_census()
     selectable = [c for c in census if c[1]]
-    assert len(selectable) == 236, len(selectable)      # 192 packed (incl. 48 SCHED) + 40 multi-pass + 4 warm-up (csrc/uavenv_capi.hip: variant_selectable)
+    assert len(selectable) == 188, len(selectable)      # 144 packed (incl. 24 SCHED) + 40 multi-pass + 4 warm-up (csrc/uavenv_capi.hip: variant_selectable)
     never = [name for name, sel, n in census if sel and n == 0]
     assert not never, "instantiations launch_env can select but no test of this module launched:\n  " + "\n  ".join(never)
     stray = [name for name, sel, n in census if not sel and n != 0]

@@ -63,48 +63,14 @@ def test_step_many_is_bit_identical_to_single_steps(shape, pin, monkeypatch):
         assert torch.equal(env.out[k], v), k
 
 
-@pytest.mark.parametrize("pin", [None, "0", "1"], ids=["auto", "unpinned", "pinned"])
-@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%denv_%dx%d_T%d" % s)
-def test_step_many_packed_unpacks_to_exactly_what_step_many_returns(shape, pin, monkeypatch):
-    """uavenv_step_many_packed (one record per walker / env and step) + uavenv_unpack_outputs == uavenv_step_many on all nine
-    arrays of every step, and the same final state: the packed-output kernels compute the same steps."""
-    torch = _torch()
-    if pin is not None:
-        monkeypatch.setenv("UAVENV_FORCE_PIN", pin)
-    n, n_bs, n_ue, T = shape
-    env = _env(n, n_bs, n_ue)
-    ref = env.clone()
-    act = _actions(torch, env, T, 6)
-    pk = env.step_many_packed(act)
-    got = env.unpack_outputs(pk)
-    want = ref.step_many(act)
-    assert set(got) == set(want)
-    for k in want:
-        assert torch.equal(got[k], want[k]), k
-    assert np.array_equal(env.get_state(), ref.get_state())
-    # the records decode on the host with the documented layouts
-    w = pk["walker"].cpu().numpy().view(env.WALKER_OUT_DTYPE)[..., 0]
-    e = pk["env"].cpu().numpy().view(env.STEP_OUT_DTYPE)[..., 0]
-    assert np.array_equal(w["ix"], want["ue_xy"][..., 0].cpu().numpy()) and np.array_equal(w["serving"], want["serving"].cpu().numpy())
-    assert np.array_equal(e["n_out"], want["n_out"].cpu().numpy()) and np.array_equal(e["done"], want["done"].cpu().numpy())
-    assert np.array_equal(e["reward"], want["reward"].cpu().numpy())
-    # a second call reuses the record buffers and continues from the stored state
-    env.step_many_packed(act, out=pk)
-    ref.step_many(act, out=want)
-    got2 = env.unpack_outputs(pk, out=got)
-    for k in want:
-        assert torch.equal(got2[k], want[k]), k
-
-
 # (n_envs, n_bs, n_ue, T, slots): W = ceil(n_envs / envs per wavefront) env-wavefronts planned onto k x `slots` slots, k = W // slots
 ROT_SHAPES = [(100, 4, 20, 7, 24), (100, 4, 20, 50, 26), (301, 4, 20, 33, 80), (50, 4, 40, 9, 37), (33, 3, 20, 6, 8), (20, 8, 20, 5, 5),
               (10, 16, 60, 6, 7), (64, 4, 20, 100, 16),
               (100, 4, 20, 21, 13), (301, 4, 20, 40, 29), (64, 4, 20, 12, 5)]      # k = 2, 3, 4 resident wavefronts per pretend-SIMD
 
 
-@pytest.mark.parametrize("packed_out", [False, True], ids=["nine_arrays", "packed_records"])
 @pytest.mark.parametrize("shape", ROT_SHAPES, ids=lambda s: "%denv_%dx%d_T%d_S%d" % s)
-def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_out, monkeypatch):
+def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, monkeypatch):
     """A multi-step call on S < W < 2 S wavefronts runs as ONE launch of S persistent wavefronts, each working through up to three pieces
     (env-wavefront, first step, steps) of a wrap-around schedule (csrc/uavenv_capi.hip: rotation_plan); the two wavefronts that share
     a split job hand its state over through memory + a flag.  Same steps, same order per env: every output of every step and the final state must equal the
@@ -127,11 +93,7 @@ def test_rotation_schedule_is_bit_identical_to_the_plain_launch(shape, packed_ou
     assert ref._lib.uavenv_debug_rotation_info(ref._h, T, C.byref(nl), C.byref(sl)) == 0 and nl.value == 0    # ... the reference does not
     act = _actions(torch, env, T, 8)
     for rep in range(3):                                                        # later calls: cached schedule, flags cleared by their consumers
-        if packed_out:
-            got = env.unpack_outputs(env.step_many_packed(act))
-            want = ref.unpack_outputs(ref.step_many_packed(act))
-        else:
-            got, want = env.step_many(act), ref.step_many(act)
+        got, want = env.step_many(act), ref.step_many(act)
         for k in want:
             assert torch.equal(got[k], want[k]), "%s differs (call %d)" % (k, rep)
         assert np.array_equal(env.get_state(), ref.get_state())
@@ -240,123 +202,6 @@ def test_rotation_is_automatic_where_it_pays_and_off_elsewhere():
         assert (nl.value == 1) == want and nl.value in (0, 1), (n, T, nl.value, n_simd)
         if nl.value:
             assert sl.value == k * n_simd
-
-
-def test_step_many_packed_rejects_bad_arguments():
-    torch = _torch()
-    import ctypes as C
-
-    from drl_uav_cellularnet_amd import _capi
-
-    env = _env(64, 4, 20)
-    act = _actions(torch, env, 2, 3)
-    pk = env.step_many_packed(act)
-    st = env.packed_out_struct(pk)
-    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), 0, C.byref(st), env._stream()) == 0
-    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), -1, C.byref(st), env._stream()) != 0
-    assert env._lib.uavenv_step_many_packed(env._h, None, 2, C.byref(st), env._stream()) != 0
-    bad = _capi.UavEnvOutPacked()
-    bad.walker_dev, bad.bs_xy_dev = st.walker_dev, st.bs_xy_dev                # env_dev missing: all three arrays are mandatory
-    assert env._lib.uavenv_step_many_packed(env._h, act.data_ptr(), 2, C.byref(bad), env._stream()) != 0
-    f64env = _env(8, 4, 20, f64_outputs=True)
-    full = {k: torch.empty((2,) + tuple(v.shape), dtype=v.dtype, device=v.device) for k, v in f64env.out.items()}
-    pk8 = f64env.step_many_packed(_actions(torch, f64env, 2, 4))
-    with pytest.raises(_capi.UavEnvError):
-        f64env.unpack_outputs(pk8, out=full)                                   # float64 copies cannot come out of float32 records
-    with pytest.raises(ValueError):
-        env.step_many_packed(act[:1], out=pk)
-
-
-def test_step_many_long_run_crosses_phases_done_and_matches_oracle():
-    """150 steps: FIFO depth 1 -> 3, aggregation phase changes (tick 200 + 100 + 10 ...), group arrivals, and MAXSTEP = 120 reached
-    inside the launch (done stays 1 and step_n keeps counting, as the reference's step() does without a reset)."""
-    torch = _torch()
-    from oracle import oracle as O
-
-    n, T = 192, 150
-    env = _env(n, 4, 20, max_step=120, seed=0x5EED)
-    ref = env.clone()
-    orc = O.OracleEnv(O.make_config(4, 20, 100, groups=[5, 5, 5, 5], max_step=120), n, seed=0x5EED)
-    orc.construct()
-    act = _actions(torch, env, T, 11)
-    out = env.step_many(act[:100])
-    out2 = env.step_many(act[100:])                                # a second call continues from the stored state
-    act_np = act.cpu().numpy()
-    for t in range(T):
-        ref.step(act[t])
-        oo = orc.step(act_np[t])
-        blk = (out, t) if t < 100 else (out2, t - 100)
-        for k, v in ref.out.items():
-            assert torch.equal(blk[0][k][blk[1]], v), "%s differs at step %d" % (k, t)
-        if t % 10 == 0 or t >= 118:
-            for k in ("ue_xy", "bs_xy", "serving", "n_out", "step_n", "done"):
-                assert np.array_equal(blk[0][k][blk[1]].cpu().numpy(), oo[k]), "oracle: %s at step %d" % (k, t)
-            for k in ("cur_sinr", "mean_sinr", "reward"):
-                np.testing.assert_allclose(blk[0][k][blk[1]].cpu().numpy(), oo[k], rtol=1e-5, atol=0)
-    assert int(out2["done"][-1].min()) == 1 and int(out2["step_n"][-1][0]) == T
-    assert int(out["done"][99].max()) == 0
-    assert np.array_equal(env.get_state(), ref.get_state())
-
-
-def test_step_many_skips_null_outputs_and_rejects_bad_arguments():
-    torch = _torch()
-    import ctypes as C
-
-    from drl_uav_cellularnet_amd import UavEnvError, _capi
-
-    env = _env(64, 4, 20)
-    ref = env.clone()
-    act = _actions(torch, env, 4, 3)
-    # only the reward block requested: the checked kernel variant, everything else NULL
-    rew = torch.empty((4, 64), dtype=torch.float32, device=env.device)
-    st = _capi.UavEnvOut()
-    st.reward_dev = rew.data_ptr()
-    _capi.check(env._lib.uavenv_step_many(env._h, act.data_ptr(), 4, C.byref(st), env._stream()))
-    for t in range(4):
-        ref.step(act[t])
-        assert torch.equal(rew[t], ref.out["reward"])
-    assert np.array_equal(env.get_state(), ref.get_state())
-    assert env._lib.uavenv_step_many(env._h, act.data_ptr(), 0, C.byref(st), env._stream()) == 0      # zero steps: a no-op
-    assert env._lib.uavenv_step_many(env._h, act.data_ptr(), -1, C.byref(st), env._stream()) != 0
-    assert env._lib.uavenv_step_many(env._h, None, 2, C.byref(st), env._stream()) != 0
-    with pytest.raises(ValueError):
-        env.step_many(act[:, :10])
-    with pytest.raises((ValueError, UavEnvError)):
-        env.step_many(act, out={"reward": rew})
-
-
-def test_step_seq_is_bit_identical_to_single_steps():
-    torch = _torch()
-    for n, n_bs, n_ue in ((4096, 4, 20), (5, 16, 200)):
-        env = _env(n, n_bs, n_ue)
-        ref = env.clone()
-        tape = _actions(torch, env, 9, 31)
-        env.step_seq(tape)
-        for t in range(9):
-            ref.step(tape[t])
-        for k, v in ref.out.items():
-            assert torch.equal(env.out[k], v), k
-        assert np.array_equal(env.get_state(), ref.get_state())
-
-
-def test_graph_replay_of_steps_is_bit_identical_to_eager():
-    torch = _torch()
-    env = _env(4096, 4, 20)
-    ref = env.clone()
-    T = 12
-    tape = _actions(torch, env, T, 21)
-    g = env.capture_steps(tape)                                    # capture executes nothing
-    assert np.array_equal(env.get_state(), ref.get_state())
-    for rep in range(3):
-        if rep:
-            tape.copy_(_actions(torch, env, T, 21 + rep))          # the graph reads the tape at replay time
-        g.replay()
-        for t in range(T):
-            ref.step(tape[t])
-        torch.cuda.synchronize()
-        for k, v in ref.out.items():
-            assert torch.equal(env.out[k], v), k
-        assert np.array_equal(env.get_state(), ref.get_state())
 
 
 @pytest.mark.parametrize("shape", [(100, 4, 20, 33), (100, 4, 20, 32), (100, 4, 20, 49), (50, 4, 40, 7), (10, 16, 200, 4), (20, 8, 20, 9), (4097, 4, 20, 2048)],

@@ -18,11 +18,11 @@ MODES = {0: "WARMUP", 1: "RESET", 2: "STEP", 3: "TRACE", 4: "RESET_TRACE"}
 
 
 def census_name(rocprof_name):
-    m = re.search(r"env_kernel_packed<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false), (true|false), (true|false)>", rocprof_name)
+    m = re.search(r"env_kernel_packed<(\d+), (\d+), (true|false), (true|false), (true|false), (true|false), (true|false)>", rocprof_name)
     if m:
         bt, mode = int(m.group(1)), int(m.group(2))
-        plc, fast, pin, many, pko, sched = [g == "true" for g in m.groups()[2:]]
-        return "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d, PKO=%d%s>" % (bt, MODES[mode], plc, fast, pin, many, pko, ", SCHED=1" if sched else "")
+        plc, fast, pin, many, sched = [g == "true" for g in m.groups()[2:]]
+        return "env_kernel_packed<BT=%d, %s, PLC=%d, FAST=%d, PIN=%d, MANY=%d%s>" % (bt, MODES[mode], plc, fast, pin, many, ", SCHED=1" if sched else "")
     m = re.search(r"env_kernel_multipass<(\d+), (\d+), (true|false), (true|false)>", rocprof_name)
     if m:
         return "env_kernel_multipass<BT=%d, %s, PLC=%d, FAST=%d>" % (int(m.group(1)), MODES[int(m.group(2))], m.group(3) == "true", m.group(4) == "true")
