@@ -1,23 +1,17 @@
 #!/bin/bash
-# actor head: correctness, then the head alone and the collection with / without the LDS-DMA stagger (UAVAGENT_HEAD_STAGGER=0: every wave issues
-# at the chunk's start), processes alternated on one box
+# actor head: tests, the head alone by row count and tile height, s_memtime stamps (ab_build/libuavagent_stamps.so = a -DUAVGEMM_STAMPS build), collection A/B
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/${1:-r04hd}
+O=$R/gpurun_out/${1:-r04hf}
 mkdir -p $O
 cd $R
-timeout -k 10 600 python -m pytest tests/test_learner_kernels_gpu.py -q -x -k "actor_head or graph_captured or index_lists" > $O/tests.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_learner_kernels_gpu.py tests/test_a2c_gpu.py tests/test_agent_kernel_gpu.py -q -x > $O/tests.log 2>&1
 rc=$?; echo "tests rc=$rc" | tee -a $O/status.txt; tail -3 $O/tests.log
 [ $rc -eq 0 ] || exit $rc
-for rep in 1 2; do
-  timeout -k 10 300 python tools/bench_head.py > $O/bench_head_stagger_$rep.json 2>> $O/err.log
-  UAVAGENT_HEAD_STAGGER=0 timeout -k 10 300 python tools/bench_head.py > $O/bench_head_nostagger_$rep.json 2>> $O/err.log
-done
-python - <<'PY'
-import json,os
-R=os.environ.get("GRAFT_REPO_ROOT",".")
-import glob
-for f in sorted(glob.glob(R+"/gpurun_out/*/bench_head_*stagger_*.json"))[-4:]:
-    d=json.load(open(f)); print(os.path.basename(f), {k:min(v) for k,v in d.items()})
-PY
-timeout -k 10 300 python tools/ab_collect.py default unsplit > $O/ab_collect_stagger.json 2>> $O/err.log; cat $O/ab_collect_stagger.json
-UAVAGENT_HEAD_STAGGER=0 timeout -k 10 300 python tools/ab_collect.py default unsplit > $O/ab_collect_nostagger.json 2>> $O/err.log; cat $O/ab_collect_nostagger.json
+timeout -k 10 300 python tools/bench_head.py > $O/bench_head.json 2>> $O/err.log
+python -c "
+import json;d=json.load(open('$O/bench_head.json'));print({k:min(v) for k,v in d.items()})"
+UAVAGENT_LIB=$R/ab_build/libuavagent_stamps.so timeout -k 10 300 python tools/head_stamps.py > $O/head_stamps.json 2>> $O/err.log
+python -c "
+import json;d=json.load(open('$O/head_stamps.json'))
+for k,v in d.items(): print(k, {a:int(b) for a,b in v['median_cycles'].items()})"
+timeout -k 10 300 python tools/ab_collect.py default unsplit > $O/ab_collect.json 2>> $O/err.log; cat $O/ab_collect.json
