@@ -140,3 +140,30 @@ def test_precompiled_timed_region_steps_the_env_like_run(launch):
     torch.cuda.synchronize()
     assert np.array_equal(env.get_state(), ref.get_state())
     assert r.t == t
+
+
+def test_traffic_entries_are_used_only_for_their_own_dispatch_form():
+    """bench.committed_counters: a committed PMC entry describes ONE dispatch form -- (kernel, batch, shape, steps
+    per call, schedule) -- and is never scaled onto another one: a run of any other form gets None and the reason."""
+    sys.path.insert(0, ROOT)
+    import json
+
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "traffic_current.json")) as f:
+        entries = json.load(f)["entries"]
+    assert entries and all({"kernel", "envs", "n_bs", "n_ue", "steps_per_launch", "schedule", "dispatches_per_call"} <= set(e) for e in entries)
+    keys = [(e["envs"], e["n_bs"], e["n_ue"], e["kernel"], e["steps_per_launch"], e["schedule"]) for e in entries]
+    assert len(set(keys)) == len(keys)                                   # one entry per form
+    assert all(abs(e["dispatches_per_call"] - 1.0) < 0.05 for e in entries)   # every committed form is one dispatch per call
+    e = next(x for x in entries if x["schedule"] == "one_launch_rotation" and x["steps_per_launch"] == 100)
+    got, why = bench.committed_counters(e["envs"], e["n_bs"], e["n_ue"], e["kernel"], 100, "one_launch_rotation")
+    assert got == e and why is None
+    for spl, sched in ((100, "plain"), (50, "one_launch_rotation"), (20, "plain")):
+        got, why = bench.committed_counters(e["envs"], e["n_bs"], e["n_ue"], e["kernel"], spl, sched)
+        assert got is None and "dispatch form" in why, (spl, sched, why)
+    got, why = bench.committed_counters(12345, 4, 20, e["kernel"], 100, "one_launch_rotation")
+    assert got is None and "batch size" in why
+    # the driver's call (20-step launches) and its plain counterpart are both committed, under their own kernels
+    forms = {(x["steps_per_launch"], x["schedule"]) for x in entries if x["envs"] == 4096 and x["n_ue"] == 20}
+    assert {(100, "one_launch_rotation"), (20, "one_launch_rotation"), (20, "plain"), (1, "plain")} <= forms
