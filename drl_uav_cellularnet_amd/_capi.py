@@ -53,7 +53,7 @@ class UavEnvStateLayout(C.Structure):
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
            "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area", "uavenv_sinr_area_at",
-           "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset", "uavenv_debug_rotation_info", "uavenv_step_many_prepare", "uavenv_device_error", "uavenv_launch_timing", "uavenv_launch_times_us",
+           "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset", "uavenv_debug_rotation_info", "uavenv_step_many_prepare", "uavenv_device_error", "uavenv_launch_timing", "uavenv_launch_times_us", "uavenv_debug_schedule",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
 
 _lib = None
@@ -106,6 +106,7 @@ def load():
     lib.uavenv_step_many_prepare.argtypes = [_P, C.c_int]
     lib.uavenv_device_error.argtypes = [_P, C.POINTER(C.c_uint32)]
     lib.uavenv_launch_timing.argtypes = [_P, C.c_int]
+    lib.uavenv_debug_schedule.argtypes = [C.c_int64, C.c_int64, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.uavenv_launch_times_us.argtypes = [_P, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
     lib.uavenv_state_layout.argtypes = [_P, C.POINTER(UavEnvStateLayout)]
     lib.uavenv_get_state.argtypes = [_P, _P, C.c_int, _P]

@@ -672,36 +672,15 @@ static UavEnvOut out_block(const UavEnvOut &o, long long t, long long N, long lo
 // profiles/r04a_many_ab_three_launch_forms.json.  Removed.)
 // Returns the index of the cached / newly built plan in h->rot_plans, or -1 when no schedule applies (then the plain launch runs).
 static long long rot_padded_slots(long long S) { return (S + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock; }
-static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
-    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < 2) return -1;
-    const long long W = (h->N + h->kp.epw - 1) / h->kp.epw;
-    const long long k_res = W / h->rot_slots;                      // wavefronts every SIMD hosts for the whole launch
-    const long long S = k_res * h->rot_slots;
-    if (k_res < 1 || W <= S) return -1;                            // fewer wavefronts than SIMDs, or a balanced batch
-    for (size_t i = 0; i < h->rot_plans->size(); ++i)
-        if ((*h->rot_plans)[i].n_steps == T) return (*h->rot_plans)[i].dev ? (int)i : -1;
-    // A new schedule needs a hipMalloc and a synchronous upload: not inside a stream capture (the plain launch runs instead, and the
-    // call is not remembered, so that a later call outside the capture builds it), cf. uavenv_step_many_prepare.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    if (cap != hipStreamCaptureStatusNone) return -1;
-    auto remember = [&](int D, int4 *dev) -> int {
-        h->rot_plans->push_back(uavenv::RotPlan{T, D, S, dev});
-        return dev ? (int)h->rot_plans->size() - 1 : -1;
-    };
-    const long long M = (W * T + S - 1) / S;                       // makespan in step-times
-    if (M - T < 1 || M >= 2 * (long long)T) return remember(0, nullptr);
-    // Automatic use only where it pays (same-box sweeps, us per step plain -> scheduled: profiles/r04a_*, r04k_many_ab_sweep.json).
-    // k = 1: one wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take (2.77 vs 4.31 us), so the schedule
-    // wins while W / S <= 1.45 (4096 envs, 1.33: 4.60 -> 3.81; 5400 envs, 1.76: 4.65 -> 4.90).  k = 2: the plain launch of more than two
-    // wavefronts per SIMD is the unpinned kernel with a third wavefront queued behind two resident ones; 2 k-resident pinned wavefronts win
-    // over the whole range (8192 envs: 7.90 -> 5.92; 9000 envs, 1.46: 7.90 -> 6.47).  k > 2 would need more than two resident wavefronts of
-    // the pinned kernel.  Every piece border costs its slot a state store (+ release) and a (poll + acquire +) state load, ~5-8 us, against
-    // ~0.7 us gained per step: 16-step calls lose (4.98 -> 5.23), 20-step calls win (4.87 -> 4.52): from 20 steps per call on.
-    if (h->rotate == -1 && (k_res > 2 || (k_res == 1 && 100 * W > 145 * S) || T < 20)) return remember(0, nullptr);
+// The schedule itself: pure host arithmetic (no device, no handle), so that the CPU test suite can check it for any (W, S, T)
+// (uavenv_debug_schedule).  -> table rows [rot_padded_slots(S)][kSchedPieces] of {env-wavefront, first step, steps, SCHED_* bits}; false
+// when no valid schedule exists for these numbers.
+static bool build_schedule(long long W, long long S, int T, bool drop_publish, std::vector<int4> &table) {
     struct Piece { int ew, t0, nt; long long time; };
     std::vector<std::vector<Piece>> cell((size_t)S);              // [slot] -> pieces
     bool ok = true;
+    const long long M = (W * T + S - 1) / S;                       // makespan in step-times
+    if (W <= S || T < 2 || M - T < 1 || M >= 2 * (long long)T) return false;
     {   // McNaughton fill.  The FIRST steps of a split job go to the next slot's start.
         long long slot = 0, t = 0;
         for (long long j = 0; j < W && ok; ++j) {
@@ -742,28 +721,78 @@ static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
         else if (z.n == 2) ok = z.slot0 >= 0 && z.slot1 >= 0 && z.slot0 != z.slot1 && z.q0 == 0 && z.len0 >= 1 && z.t1 == z.len0 && z.len0 + z.len1 == T;
         else ok = false;
     }
-    if (!ok) return remember(0, nullptr);
+    if (!ok) return false;
     // One table row per WAVEFRONT of the launch, not per slot: a launch of S slots has ceil(S / kWavesPerBlock) whole workgroups, and the
     // wavefronts past slot S - 1 of the last one read rows too -- theirs are all-zero (no steps).  (Round 3, first GPU run: with rows
     // per slot those wavefronts read past the allocation: a memory fault at S = 26.)
     const long long Sp = rot_padded_slots(S);
-    std::vector<int4> table((size_t)(Sp * kSchedPieces), int4{0, 0, 0, 0});
+    table.assign((size_t)(Sp * kSchedPieces), int4{0, 0, 0, 0});
     for (long long sl = 0; sl < S; ++sl) {
         const auto &c = cell[(size_t)sl];
         for (size_t q = 0; q < c.size(); ++q) {         // column by kind: 0 publishes (it is the slot's first piece, verified above), 1 whole, 2 waits
             int bits = 0, col = 1;
             if (c[q].t0 > 0) { bits |= SCHED_WAIT; col = 2; }
-            if (c[q].t0 + c[q].nt < T) { col = 0; if (!h->drop_publish) bits |= SCHED_PUBLISH; }
+            if (c[q].t0 + c[q].nt < T) { col = 0; if (!drop_publish) bits |= SCHED_PUBLISH; }
             int4 &cellq = table[(size_t)(sl * kSchedPieces) + (size_t)col];
             if (cellq.z != 0) ok = false;                // (two pieces of one kind in a slot: cannot happen for M < 2 T)
             cellq = int4{c[q].ew, c[q].t0, c[q].nt, bits};
         }
     }
-    if (!ok) return remember(0, nullptr);
+    if (!ok) return false;
+    return ok;
+}
+
+static int rotation_plan(uavenv_t *h, int T, hipStream_t stream) {
+    if (!h->packed || !h->rot_plans || h->rotate == 0 || T < 2) return -1;
+    const long long W = (h->N + h->kp.epw - 1) / h->kp.epw;
+    const long long k_res = W / h->rot_slots;                      // wavefronts every SIMD hosts for the whole launch
+    const long long S = k_res * h->rot_slots;
+    if (k_res < 1 || W <= S) return -1;                            // fewer wavefronts than SIMDs, or a balanced batch
+    for (size_t i = 0; i < h->rot_plans->size(); ++i)
+        if ((*h->rot_plans)[i].n_steps == T) return (*h->rot_plans)[i].dev ? (int)i : -1;
+    // A new schedule needs a hipMalloc and a synchronous upload: not inside a stream capture (the plain launch runs instead, and the
+    // call is not remembered, so that a later call outside the capture builds it), cf. uavenv_step_many_prepare.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (cap != hipStreamCaptureStatusNone) return -1;
+    auto remember = [&](int D, int4 *dev) -> int {
+        h->rot_plans->push_back(uavenv::RotPlan{T, D, S, dev});
+        return dev ? (int)h->rot_plans->size() - 1 : -1;
+    };
+    const long long M = (W * T + S - 1) / S;                       // makespan in step-times
+    if (M - T < 1 || M >= 2 * (long long)T) return remember(0, nullptr);
+    // Automatic use only where it pays (same-box sweeps, us per step plain -> scheduled: profiles/r04a_*, r04k_many_ab_sweep.json).
+    // k = 1: one wavefront alone on a SIMD runs a step in ~0.64 of the time two co-resident ones take (2.77 vs 4.31 us), so the schedule
+    // wins while W / S <= 1.45 (4096 envs, 1.33: 4.60 -> 3.81; 5400 envs, 1.76: 4.65 -> 4.90).  k = 2: the plain launch of more than two
+    // wavefronts per SIMD is the unpinned kernel with a third wavefront queued behind two resident ones; 2 k-resident pinned wavefronts win
+    // over the whole range (8192 envs: 7.90 -> 5.92; 9000 envs, 1.46: 7.90 -> 6.47).  k > 2 would need more than two resident wavefronts of
+    // the pinned kernel.  Every piece border costs its slot a state store (+ release) and a (poll + acquire +) state load, ~5-8 us, against
+    // ~0.7 us gained per step: 16-step calls lose (4.98 -> 5.23), 20-step calls win (4.87 -> 4.52): from 20 steps per call on.
+    if (h->rotate == -1 && (k_res > 2 || (k_res == 1 && 100 * W > 145 * S) || T < 20)) return remember(0, nullptr);
+    std::vector<int4> table;
+    if (!build_schedule(W, S, T, h->drop_publish != 0, table)) return remember(0, nullptr);
     int4 *dev = nullptr;
     if (hipMalloc((void **)&dev, table.size() * sizeof(int4)) != hipSuccess) return remember(0, nullptr);
     if (hipMemcpy(dev, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return remember(0, nullptr); }
     return remember(1, dev);
+}
+
+// Test hook without a device: the schedule of W env-wavefronts on S slots for T steps.  table_out: int32 [rows][3 pieces][4] (may be NULL to
+// ask for the size only); *rows_out = rows (slots padded to whole workgroups), *makespan_out = ceil(W T / S).  UAVENV_E_INVALID when no
+// schedule exists for these numbers (W <= S, W >= 2 S, T < 2, ...).
+extern "C" int uavenv_debug_schedule(int64_t n_wavefronts, int64_t n_slots, int n_steps, int32_t *table_out, int64_t table_capacity_rows,
+                                     int64_t *rows_out, int64_t *makespan_out) {
+    if (n_wavefronts < 1 || n_slots < 1 || n_steps < 1) return fail(UAVENV_E_INVALID, "debug_schedule: bad argument");
+    std::vector<int4> table;
+    if (!build_schedule(n_wavefronts, n_slots, n_steps, false, table)) return fail(UAVENV_E_INVALID, "debug_schedule: no schedule for these numbers");
+    const long long rows = (long long)table.size() / kSchedPieces;
+    if (rows_out) *rows_out = rows;
+    if (makespan_out) *makespan_out = (n_wavefronts * n_steps + n_slots - 1) / n_slots;
+    if (table_out) {
+        if (table_capacity_rows < rows) return fail(UAVENV_E_INVALID, "debug_schedule: table_out too small");
+        std::memcpy(table_out, table.data(), table.size() * sizeof(int4));
+    }
+    return UAVENV_OK;
 }
 
 extern "C" int uavenv_step_many_prepare(uavenv_t *h, int n_steps) {

@@ -219,6 +219,14 @@ int uavenv_debug_rotation_info(uavenv_t *h, int n_steps, int *n_launches, long l
 int uavenv_launch_timing(uavenv_t *h, int enable);
 int uavenv_launch_times_us(uavenv_t *h, double *us_out, int max_out, int *n_out);
 
+/* Test hook that needs NO device: the schedule itself for n_wavefronts env-wavefronts on n_slots slots and n_steps steps (pure host
+ * arithmetic; the CPU test suite checks its invariants for many shapes).  table_out: int32 [rows][3][4] = per slot-row its three pieces
+ * {env-wavefront, first step, steps, bits (1 = waits for a hand-off, 2 = publishes one)} in the column order publish / whole / wait, or
+ * NULL to ask for the size; *rows_out = rows (slots padded to whole workgroups; the padding rows are all-zero), *makespan_out = ceil(W T / S)
+ * step-times.  UAVENV_E_INVALID when no schedule exists for these numbers (W <= S, ceil(W T / S) >= 2 T, n_steps < 2, ...). */
+int uavenv_debug_schedule(int64_t n_wavefronts, int64_t n_slots, int n_steps, int32_t *table_out, int64_t table_capacity_rows,
+                          int64_t *rows_out, int64_t *makespan_out);
+
 /* Sticky device-side error of a handle: *code = 0, or the word a kernel left when it gave up (0x48414e44 "HAND": a wavefront of a
  * one-launch schedule waited longer than the spin budget for the wavefront that runs the first steps of the same envs -- never seen
  * outside the test hook, but a bounded wait is what turns a scheduling bug into an error code instead of a hung GPU).  The word lives
