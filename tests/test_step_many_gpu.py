@@ -234,3 +234,40 @@ def test_step_range_over_two_ranges_equals_step(shape):
         env.step_range(act[0], n, 1)
     with pytest.raises(_capi.UavEnvError, match="range"):
         env.step_range(act[0], 0, 0)
+
+
+def test_one_launch_rotation_under_uneven_load_many_calls(monkeypatch):
+    """Hand-offs under UNEVEN load (MI355X_MICROARCH.md: 'test every hand-off under uneven load ... checking every word'): 60 scheduled 20-step
+    calls at BASELINE's 4096 envs while a second stream keeps part of the chip busy with large GEMMs and copies; every output word of every
+    call and the state after the last one must equal the plain launch's (which ran alone).  A stale or early hand-off would show as a
+    difference in some env's trajectory from that call on."""
+    torch = _torch()
+    env = _env(4096, 4, 20)                                       # default handle: the schedule is automatic from 20 steps per call on
+    monkeypatch.setenv("UAVENV_ROTATE", "0")
+    ref = env.clone()
+    import ctypes as C
+
+    nl = C.c_int(-1)
+    assert env._lib.uavenv_debug_rotation_info(env._h, 20, C.byref(nl), None) == 0
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert nl.value == 1
+    acts = [_actions(torch, env, 20, 100 + i) for i in range(6)]
+    want = []
+    for i in range(60):
+        want.append({k: v.clone() for k, v in ref.step_many(acts[i % 6]).items()})
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    stop = 60
+    for i in range(stop):
+        with torch.cuda.stream(side):                             # load that comes and goes: a GEMM, then a 64 MB copy
+            if i % 3 != 2:
+                torch.mm(a, a)
+            if i % 2 == 0:
+                big.copy_(big.flip(0)[: big.numel()])
+        got = env.step_many(acts[i % 6])
+        for k in want[i]:
+            assert torch.equal(got[k], want[i][k]), "%s differs in call %d" % (k, i)
+    torch.cuda.synchronize()
+    assert np.array_equal(env.get_state(), ref.get_state()) and env.device_error() == 0
