@@ -42,7 +42,14 @@ class UavEnvOut(C.Structure):
     _fields_ = [(n + "_dev", _P) for n in OUT_FIELDS]
 
 
-ABI_VERSION = 6   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
+class UavEnvGatedRollout(C.Structure):      # include/uavenv.h
+    _fields_ = [("n_steps", C.c_int32), ("actions_dev", C.c_void_p), ("gate_actions_dev", C.c_void_p), ("gate_obs_dev", C.c_void_p),
+                ("reward_dev", C.c_void_p), ("enc_table_a_dev", C.c_void_p), ("enc_bias_a_dev", C.c_void_p), ("enc_out_a_dev", C.c_void_p),
+                ("enc_table_c_dev", C.c_void_p), ("enc_bias_c_dev", C.c_void_p), ("enc_out_c_dev", C.c_void_p), ("idx_out_dev", C.c_void_p),
+                ("enc_rows", C.c_int64), ("enc_hidden", C.c_int32), ("enc_relu6", C.c_int32)]
+
+
+ABI_VERSION = 7   # UAVENV_ABI_VERSION of include/uavenv.h this binding is written against (tests/test_capi_load.py compares the three)
 STATE_FIELDS = ("ue_pos", "ue_aux", "grp", "env", "bs_xy", "out_bits")   # arrays of records, include/uavenv.h
 
 
@@ -51,7 +58,7 @@ class UavEnvStateLayout(C.Structure):
 
 
 EXPORTS = ("uavenv_abi_version", "uavenv_last_error", "uavenv_default_config", "uavenv_create", "uavenv_destroy",
-           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
+           "uavenv_init", "uavenv_warmup", "uavenv_reset", "uavenv_reset_trace", "uavenv_step", "uavenv_step_range", "uavenv_rollout_gated", "uavenv_step_many", "uavenv_step_seq", "uavenv_step_trace",
            "uavenv_obs_dense", "uavenv_obs_dense_update", "uavenv_sinr_area", "uavenv_sinr_area_at",
            "uavenv_debug_variant_count", "uavenv_debug_variant_info", "uavenv_debug_variant_reset", "uavenv_debug_rotation_info", "uavenv_step_many_prepare", "uavenv_device_error", "uavenv_launch_timing", "uavenv_launch_times_us", "uavenv_debug_schedule",
            "uavenv_state_layout", "uavenv_get_state", "uavenv_set_state", "uavenv_philox4x32_10", "uavenv_lean_math_eval")
@@ -91,6 +98,7 @@ def load():
     lib.uavenv_reset.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_reset_trace.argtypes = [_P, _P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step.argtypes = [_P, _P, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
+    lib.uavenv_rollout_gated.argtypes = [_P, C.POINTER(UavEnvGatedRollout), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_range.argtypes = [_P, _P, C.c_int64, C.c_int64, C.POINTER(UavEnvInject), C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_many.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]
     lib.uavenv_step_seq.argtypes = [_P, _P, C.c_int, C.POINTER(UavEnvOut), _P]

@@ -243,6 +243,53 @@ class BatchedMobiEnv:
         if rc:
             _capi.check(rc)
 
+    GATE_ROWS = 16          # UAVENV_GATE_ROWS: envs per gate word of rollout_gated
+
+    def rollout_gated(self, actions, gate_actions, gate_obs, table_a, bias_a, out_a, table_c=None, bias_c=None, out_c=None, idx_out=None,
+                      reward_out=None, relu6=True):
+        """uavenv_rollout_gated: T = len(actions) steps in ONE persistent launch that takes its actions from a policy kernel running
+        beside it on another stream (include/uavenv.h has the protocol).  ``actions`` int64 [T, N] (written by the policy while this
+        launch runs), ``gate_actions`` / ``gate_obs`` int32 [ceil(N / 16)] step counters, tables float32 [n_rows, hidden], outputs
+        float32 [T, N, hidden] (slot t + 1 written after step t), ``idx_out`` int64 [T + 1, N, B + U], ``reward_out`` float32 [T, N].
+        Asynchronous; a partner that never arrives ends in device_error() != 0, not in a hang."""
+        T, N = int(actions.shape[0]), self.n_envs
+        nb = (N + self.GATE_ROWS - 1) // self.GATE_ROWS
+
+        def chk(t, dtype, shape, what):
+            if not (isinstance(t, torch.Tensor) and t.dtype == dtype and t.device == self.device and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+                raise ValueError("%s must be a contiguous %s %s tensor on the env's device" % (what, dtype, list(shape)))
+        chk(actions, torch.int64, (T, N), "actions")
+        chk(gate_actions, torch.int32, (nb,), "gate_actions")
+        chk(gate_obs, torch.int32, (nb,), "gate_obs")
+        rows, hid = int(table_a.shape[0]), int(table_a.shape[1])
+        chk(table_a, torch.float32, (rows, hid), "table_a")
+        chk(out_a, torch.float32, (T, N, hid), "out_a")
+        if bias_a is not None:
+            chk(bias_a, torch.float32, (hid,), "bias_a")
+        if table_c is not None:
+            chk(table_c, torch.float32, (rows, hid), "table_c")
+            chk(out_c, torch.float32, (T, N, hid), "out_c")
+            if bias_c is not None:
+                chk(bias_c, torch.float32, (hid,), "bias_c")
+        if idx_out is not None:
+            chk(idx_out, torch.int64, (T + 1, N, self.nBS + self.nUE), "idx_out")
+        if reward_out is not None:
+            chk(reward_out, torch.float32, (T, N), "reward_out")
+        r = _capi.UavEnvGatedRollout()
+        r.n_steps = T
+        r.actions_dev, r.gate_actions_dev, r.gate_obs_dev = actions.data_ptr(), gate_actions.data_ptr(), gate_obs.data_ptr()
+        r.reward_dev = reward_out.data_ptr() if reward_out is not None else None
+        r.enc_table_a_dev, r.enc_out_a_dev = table_a.data_ptr(), out_a.data_ptr()
+        r.enc_bias_a_dev = bias_a.data_ptr() if bias_a is not None else None
+        r.enc_table_c_dev = table_c.data_ptr() if table_c is not None else None
+        r.enc_bias_c_dev = bias_c.data_ptr() if (table_c is not None and bias_c is not None) else None
+        r.enc_out_c_dev = out_c.data_ptr() if table_c is not None else None
+        r.idx_out_dev = idx_out.data_ptr() if idx_out is not None else None
+        r.enc_rows, r.enc_hidden, r.enc_relu6 = rows, hid, 1 if relu6 else 0
+        rc = self._lib.uavenv_rollout_gated(self._h, C.byref(r), self._out_ref, self._stream())
+        if rc:
+            _capi.check(rc)
+
     def capture_steps(self, actions):
         """A hipGraph of len(actions) step() launches (one kernel node per step, step t reading ``actions[t]``): ``g.replay()``
         then costs one graph launch instead of T host calls -- the per-step host cost (ctypes call + hipLaunchKernel, ~8 us

@@ -11,9 +11,11 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 SRC = os.path.join(PKG_DIR, "csrc", "uavenv_capi.hip")
-DEPS = [SRC] + [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "philox.h", "lean_math.h", "intdiv.h",
-                                                            "state_layout.h")] + [
-    os.path.join(ROOT, "include", "uavenv.h")]
+ENV_SRCS = [SRC, os.path.join(PKG_DIR, "csrc", "uavenv_gated.hip")]     # one object per translation unit: a change to one does not rebuild the other
+ENV_HDRS = [os.path.join(PKG_DIR, "csrc", f) for f in ("uavenv_kernels.h", "uavenv_handle.h", "philox.h", "lean_math.h", "intdiv.h",
+                                                        "state_layout.h")] + [os.path.join(ROOT, "include", "uavenv.h")]
+ENV_EXTRA = {"uavenv_gated.hip": [os.path.join(PKG_DIR, "csrc", "uavenv_gated_kernel.h")]}      # headers of one translation unit only
+DEPS = ENV_SRCS + ENV_HDRS + [h for hs in ENV_EXTRA.values() for h in hs]
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB = os.path.join(LIB_DIR, "libuavenv.so")
 AGENT_SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("agent_kernels.hip", "agent_learner.hip", "agent_gemm.hip")]
@@ -59,10 +61,26 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs at wave launch (the packed env
     # kernel starts its global loads from them while the parameter struct is still being fetched)
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16", *extra_flags, "-o", LIB, SRC]
+    flags = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+             *extra_flags]
+    tag = os.path.join(obj_dir, "flags.txt")
+    same_flags = os.path.isfile(tag) and open(tag).read() == " ".join(flags)
+    objs = []
+    for src in ENV_SRCS:
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not same_flags or _stale(obj, [src] + ENV_HDRS + ENV_EXTRA.get(os.path.basename(src), [])):
+            cmd = [hipcc_path(), *flags, "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    with open(tag, "w") as f:
+        f.write(" ".join(flags))
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

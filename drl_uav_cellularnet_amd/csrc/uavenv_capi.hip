@@ -13,78 +13,25 @@
 #include <string>
 #include <vector>
 
-#include "../../include/uavenv.h"
-#include "uavenv_kernels.h"
+#include "uavenv_handle.h"
 
 using namespace uavk;
+using uavenv_internal::fail;
+using uavenv_internal::poisoned;
+using uavenv_internal::fill_call;
+using uavenv_internal::call_is_fast;
 
 static_assert(UAVENV_MAX_GROUPS == kMaxGroups && UAVENV_MAX_BS == kMaxBs, "header / kernel bounds differ");
 
-struct uavenv {
-    UavEnvConfig cfg;
-    long long N;
-    int device;
-    uint64_t seed;
-    uint32_t env_id_base;
-    int bt;  // template bound on B
-    bool plc;  // pl_b == 30: cube path-loss kernel variant
-    bool packed;  // U <= 64 and U >= max(B, Gr): env_kernel_packed with kp.epw envs per wavefront
-    long long n_simd;  // 4 x compute units of the device: wavefront demand per SIMD decides the PIN variant
-    char *blob;
-    int32_t *bs_init_dev;
-    long long *act_pow_dev;
-    uint4 *act_dec_dev;  // [B] split decode of the joint action (KParams::act_dec)
-    int8_t *gid_dev;  // [max(U,64)] RPGM group of walker u
-    int32_t *obs_prev_dev;  // [N, U+B] cells written by the last obs_dense(_update) call; allocated on first use
-    const float *obs_last_dev;  // the buffer that call wrote: obs_dense_update refuses any other
-    struct RotPlan { int n_steps; int n_launches; long long slots; int4 *dev; };   // rotation schedules built so far (one per n_steps;
-                                                                                  // n_launches 0 = none applies: plain launch)
-    std::vector<RotPlan> *rot_plans;
-    int rotate;         // UAVENV_ROTATE read once at create: -1 unset (automatic), 0 never, 1 whenever a schedule exists (tests)
-    long long rot_slots;  // UAVENV_ROTATE_SLOTS (tests: pretend the device has this many SIMDs), else n_simd
-    uint32_t *sched_flag_dev;   // [env-wavefronts] hand-off words of the one-launch schedule (zero between calls)
-    uint32_t *err_host, *err_dev;   // sticky device-side error word: host-mapped memory, so that every entry point can test it without a HIP call
-    uint32_t spin_us;   // hand-off spin budget (UAVENV_HANDOFF_SPIN_US, default 2 s)
-    int drop_publish;   // UAVENV_DEBUG_DROP_PUBLISH=1 (test hook): schedules are built WITHOUT their publish bits, so every hand-off times out
-    // uavenv_launch_timing: start / stop events attached to the multi-step dispatches themselves (hipExtLaunchKernelGGL: the timestamps of
-    // the dispatch packet, no marker packets around it), a ring of kTimedLaunches pairs
-    std::vector<hipEvent_t> *tev;
-    int timing, n_timed;
-    int force_pin;  // UAVENV_FORCE_PIN read ONCE at create (experiments: tools/pin_sweep.sh): -1 unset, 0 / 1 forced
-    UavEnvStateLayout lay;
-    KParams kp;  // constants + state pointers, per-call fields patched at launch
-};
-
-constexpr int kTimedLaunches = 256;
 static thread_local std::string g_err;
-
-static int fail(int code, const std::string &msg) {
+int uavenv_internal::fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess)                                                                      \
-            return fail(UAVENV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
-    } while (0)
-
-// Launches go to the handle's device whatever the caller's current device is; restored on return.
-struct DeviceGuard {
-    int prev = -1, want;
-    explicit DeviceGuard(int dev) : want(dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != want) (void)hipSetDevice(want);
-    }
-    ~DeviceGuard() {
-        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
-    }
-};
-
 // A kernel that gave up on a hand-off (uavenv_kernels.h: sched_hand_off_wait) leaves a word in host-mapped memory.  The handle's state
 // is then incomplete: every later call on it fails until uavenv_set_state() installs a whole state again.
-static int poisoned(const uavenv *h, const char *what) {
+int uavenv_internal::poisoned(const uavenv *h, const char *what) {
     if (h->err_host && *(volatile uint32_t *)h->err_host != 0u) {
         char buf[200];
         std::snprintf(buf, sizeof buf, "%s: an earlier multi-step launch on this handle failed on the device (code 0x%08x: a hand-off between two "
@@ -411,7 +358,7 @@ extern "C" int uavenv_init(uavenv_t *h, const UavEnvInitInject *inj, void *strea
 
 // FAST kernels: no injected draws, all nine standard outputs present, no float64 copies (see UAV_OUT in
 // uavenv_kernels.h).  Anything else runs the checked variant of the same kernel.
-static bool call_is_fast(const KParams &p) {
+bool uavenv_internal::call_is_fast(const KParams &p) {
     const OutPtrs &o = p.out;
     return !p.inj_theta && !p.inj_group && !p.inj_fading && o.reward && o.done && o.mean_sinr && o.n_out && o.ue_xy &&
            o.bs_xy && o.serving && o.cur_sinr && o.step_n && !o.cur_sinr_f64 && !o.mean_sinr_f64 && !o.reward_f64;
@@ -577,7 +524,7 @@ static int launch_env(uavenv_t *h, const KParams &p_in, hipStream_t s, long long
     return UAVENV_OK;
 }
 
-static void fill_call(KParams &p, const UavEnvInject *inj, const UavEnvOut *out) {
+void uavenv_internal::fill_call(KParams &p, const UavEnvInject *inj, const UavEnvOut *out) {
     p.inj_theta = inj ? inj->theta_u_dev : nullptr;
     p.inj_group = inj ? inj->group_u_dev : nullptr;
     p.inj_fading = inj ? inj->fading_dev : nullptr;

@@ -684,7 +684,7 @@ __device__ __forceinline__ void out_skip_steps(OutPtrs &o, long long t0, long lo
 // ================================================================================================
 // state construction: ue_mobility.py:433-451 + mobile_env.py:58-59.  `per` threads per env.
 // ================================================================================================
-__global__ __launch_bounds__(256) void init_kernel(InitParams p) {
+static __global__ __launch_bounds__(256) void init_kernel(InitParams p) {   // (static: the header is included by two translation units)
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int U = p.U, Gr = p.Gr, per = p.per;  // per = max(U, Gr, B, W64) threads per env
     if (tid >= p.N * per) return;
@@ -742,12 +742,16 @@ __global__ __launch_bounds__(256) void init_kernel(InitParams p) {
 // The kernel proper: `ew` = the env-wavefront this wavefront hosts (envs ew*EPW .. ew*EPW+EPW-1), `t0` / `nt` = first step and
 // number of steps (multi-step launches; a plain launch runs env-wavefront = hardware wavefront and all of p.n_ticks).
 // HO (pieces of a one-launch schedule): bit 0 = this piece continues a job another wavefront started (state LOADED coherently),
-// bit 1 = another wavefront continues this piece's job (state STORED coherently); 0 everywhere else.
+// bit 1 = another wavefront continues this piece's job (state STORED coherently); 0 everywhere else.  Bit 2 (the gated rollout kernel,
+// env_kernel_gated): the ACTIONS are loaded coherently too -- another kernel wrote them while this one was running.
+// `po` (single-step launches): where the outputs go instead of p.out (the gated rollout kernel moves the reward pointer on per step).
 template <int BT, int MODE, bool PLC, bool FAST, bool PIN, bool MANY, int HO = 0>
 __device__ __forceinline__ void env_packed_body(char *blob, const long long *actions, const int8_t *gid_of_u, long long N, int U, int EPW,
                                                 int Gr, int B_rt, int lane_magic, const KParams &p, int (*s_bs)[kMaxEpw][2 * kMaxBs],
-                                                const int wave, const long long ew, const int t0, const int nt, const int e_lo, const int e_hi) {
-    constexpr bool LDC = (HO & 1) != 0, STC = (HO & 2) != 0;
+                                                const int wave, const long long ew, const int t0, const int nt, const int e_lo, const int e_hi,
+                                                const OutPtrs *po = nullptr) {
+    constexpr bool LDC = (HO & 1) != 0, STC = (HO & 2) != 0, ACC = (HO & 4) != 0;
+    const OutPtrs &pout = po != nullptr ? *po : p.out;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
     (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5; (void)ts6;
     UAV_STAMP(ts0);                                   // wave start
@@ -792,11 +796,11 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
 #pragma unroll
             for (int b = 0; b < BT; ++b)
                 if (b < B) { const int2 q = is_reset(MODE) ? ldx(cells, c0 + (uint32_t)b) : ldx_c<LDC>(cells, c0 + (uint32_t)b); bsx[b] = q.x; bsy[b] = q.y; }
-            if (is_step(MODE)) act = ldx(actions, e32);
+            if (is_step(MODE)) act = ldx_c<ACC>(actions, e32);
         } else if (bown) {
             if (is_reset(MODE)) { bx = p.bs_init[2 * ul]; by = p.bs_init[2 * ul + 1]; }
             else { const int2 q = ldx_c<LDC>(reinterpret_cast<const int2 *>(st.bs_xy), ib32); bx = q.x; by = q.y; }
-            if (is_step(MODE)) { act = ldx(actions, e32); apw = p.act_pow[ul]; }
+            if (is_step(MODE)) { act = ldx_c<ACC>(actions, e32); apw = p.act_pow[ul]; }
         }
     }
     const EnvRec erec = ldx_c<LDC>(st.env, e32);                      // tick, phase counters, FIFO depth, step count: one record
@@ -989,10 +993,10 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
         // warm-up leaves serving and the FIFO rows as loaded; a reset overwrites serving and row 0 only (depth becomes 1)
         stx_c<STC>(st.ue_aux, iw, UeAux{hu, (int16_t)ix, (int16_t)iy, (int8_t)serving, (int8_t)r0, (int8_t)r1, (int8_t)r2});
         if (MODE != MODE_WARMUP && !MANY) {
-            if (UAV_OUT(p.out.ue_xy)) { stx(p.out.ue_xy, 2u * iw, (int16_t)ix); stx(p.out.ue_xy, 2u * iw + 1u, (int16_t)iy); }
-            if (UAV_OUT(p.out.serving)) stx(p.out.serving, iw, (int8_t)serving);
-            if (UAV_OUT(p.out.cur_sinr)) stx(p.out.cur_sinr, iw, (float)cur);
-            if (UAV_OUT64(p.out.cur_sinr_f64)) stx(p.out.cur_sinr_f64, iw, cur);
+            if (UAV_OUT(pout.ue_xy)) { stx(pout.ue_xy, 2u * iw, (int16_t)ix); stx(pout.ue_xy, 2u * iw + 1u, (int16_t)iy); }
+            if (UAV_OUT(pout.serving)) stx(pout.serving, iw, (int8_t)serving);
+            if (UAV_OUT(pout.cur_sinr)) stx(pout.cur_sinr, iw, (float)cur);
+            if (UAV_OUT64(pout.cur_sinr_f64)) stx(pout.cur_sinr_f64, iw, cur);
         }
     }
     if (gown) {
@@ -1002,13 +1006,13 @@ __device__ __forceinline__ void env_packed_body(char *blob, const long long *act
     if (bown) {
         const uint32_t bw = block_local<!PIN>(ib32);
         stx_c<STC>(st.bs_xy, 2u * bw, bx); stx_c<STC>(st.bs_xy, 2u * bw + 1u, by);
-        if (!MANY) { if (UAV_OUT(p.out.bs_xy)) { stx(p.out.bs_xy, 2u * bw, bx); stx(p.out.bs_xy, 2u * bw + 1u, by); } }
+        if (!MANY) { if (UAV_OUT(pout.bs_xy)) { stx(pout.bs_xy, 2u * bw, bx); stx(pout.bs_xy, 2u * bw + 1u, by); } }
     }
     if (head) {
         const uint32_t ew = block_local<!PIN>(e32);
         if (MODE != MODE_WARMUP) stx_c<STC>(st.out_bits, ew, ob);                                // :116 / :173
         // (MANY: outputs of the LAST step + the record; depth / step_n are the values that step started from)
-        env_finish<MODE, FAST, true, true, STC>(p, MANY ? om : p.out, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
+        env_finish<MODE, FAST, true, true, STC>(p, MANY ? om : pout, st, ew, erec, tick, agg, deagg, depth, step_n, sum_cur, n_outage);
     }
 #ifdef UAVENV_STAMPS
     UAV_STAMP(ts6);                                   // all stores issued (not yet acknowledged)

@@ -23,13 +23,14 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 6   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
+#define UAVENV_ABI_VERSION 7   /* 2: state blob = arrays of records (UavEnvStateLayout); 3: + uavenv_step_many, uavenv_step_seq;
                                 * 4: + uavenv_sinr_area_at, uavenv_step_many_packed / uavenv_unpack_outputs, uavenv_debug_variant_* (launch census), uavenv_debug_rotation_info,
                                 *      uavenv_step_many_prepare;
                                 * 5: + UAVENV_E_DEVICE, uavenv_device_error (one-launch rotation schedule with bounded hand-offs), uavenv_step_range,
                                 *      uavenv_launch_timing / uavenv_launch_times_us;
                                 * 6: - uavenv_step_many_packed / uavenv_unpack_outputs (ABI 4's packed output records: no benefit once measured
-                                *      under the one-launch schedule, removed with their 24 kernel instantiations per shape) */
+                                *      under the one-launch schedule, removed with their 24 kernel instantiations per shape);
+                                * 7: + uavenv_rollout_gated / UavEnvGatedRollout (a whole rollout as one persistent launch beside a persistent policy kernel) */
 #define UAVENV_MAX_GROUPS 16
 #define UAVENV_MAX_BS 32
 
@@ -226,6 +227,47 @@ int uavenv_launch_times_us(uavenv_t *h, double *us_out, int max_out, int *n_out)
  * step-times.  UAVENV_E_INVALID when no schedule exists for these numbers (W <= S, ceil(W T / S) >= 2 T, n_steps < 2, ...). */
 int uavenv_debug_schedule(int64_t n_wavefronts, int64_t n_slots, int n_steps, int32_t *table_out, int64_t table_capacity_rows,
                           int64_t *rows_out, int64_t *makespan_out);
+
+/* A whole ROLLOUT -- T x (MobiEnvironment.step, mobile_env.py:150-194, + the observation of mobile_env.py:169-170 encoded for the policy) --
+ * as ONE persistent kernel launch that runs BESIDE a persistent policy kernel of the caller (the learner's uavagent_actor_head_gated_f32,
+ * include/uavagent.h), for the rollout loop of a2c_single_thread.py:113-133: choose_action -> env.step -> next observation, T times, with no
+ * kernel boundary and no host in between.  The two kernels synchronise per BLOCK of UAVENV_GATE_ROWS = 16 consecutive envs through two words
+ * in device memory (monotonic step counters; the caller zeroes / presets them before every rollout):
+ *     gate_actions_dev[b] >= t + 1 : the actions of step t of block b are in actions_dev[t][16 b .. 16 b + 15]   (policy -> env)
+ *     gate_obs_dev[b]     >= t + 1 : the encoded observation BEFORE step t of block b is in enc_out_*[t][16 b ..] (env -> policy; t = 0 is the
+ *                                    caller's: it encodes the state the rollout starts from and presets the word to 1)
+ * The policy must write actions (and this kernel writes its encodings) with agent-scope coherent stores, wait for them to complete
+ * (s_waitcnt vmcnt(0)), then store the counter; readers poll with agent-scope loads.  Every wait is BOUNDED (UAVENV_HANDOFF_SPIN_US, default
+ * 2 s): a partner that never arrives -- not launched, not co-resident, crashed -- leaves error word 0x47415445 "GATE", the kernel exits and
+ * the handle answers UAVENV_E_DEVICE until uavenv_set_state (uavenv_device_error).  The caller must launch both kernels on DIFFERENT streams
+ * (or parallel branches of one graph) so that they can run at the same time; this one occupies min(blocks / 2, CUs) workgroups of 8
+ * wavefronts with more than 128 VGPRs each on purpose, so that exactly one of them and one partner workgroup (8 wavefronts x <= 88 VGPRs,
+ * any LDS) fit a CU in whatever order the dispatcher meets them.
+ * The encoder is the first dense layer of main.py:147 / :153 applied to the raveled one-hot state of main.py:190 without forming it:
+ * per env the B + U observation nodes (UAV k in plane 0 at its cell, UE in plane 1 + serving UAV) select rows (plane * G + x) * G + y of one
+ * or two float32 tables [n_rows][hidden] (hidden a multiple of 4, <= 256; rows summed in node order, + bias, optionally relu6; a node off the
+ * grid or a row >= n_rows contributes nothing): bit-identical to uavagent_first_layer_from_obs_f32.  enc_out_* are [T][N][hidden]: slot t + 1
+ * is written after step t, for t + 1 < T.  idx_out_dev (optional) is [T + 1][N][B + U] int64: slot t + 1 = the row indices after step t.
+ * reward_dev (optional) [T][N]: the reward of step t; every other output of `out` is overwritten each step as by uavenv_step, and `out`
+ * must hold all nine standard outputs.  State, outputs and rewards are bit-identical to T calls of uavenv_step with the same actions.
+ * n_ue <= 64 and n_bs == 4 (the reference's shape), on-device randomness only; UAVENV_E_INVALID otherwise. */
+#define UAVENV_GATE_ROWS 16
+typedef struct UavEnvGatedRollout {
+    int32_t n_steps;
+    const int64_t *actions_dev;          /* [T][N], written by the policy kernel while this launch runs */
+    uint32_t *gate_actions_dev;          /* [ceil(N / 16)] */
+    uint32_t *gate_obs_dev;              /* [ceil(N / 16)] */
+    float *reward_dev;                   /* [T][N] or NULL */
+    const float *enc_table_a_dev, *enc_bias_a_dev;   /* [n_rows][hidden], [hidden] (bias may be NULL) */
+    float *enc_out_a_dev;                /* [T][N][hidden] */
+    const float *enc_table_c_dev, *enc_bias_c_dev;   /* a second table over the same rows, or NULL */
+    float *enc_out_c_dev;
+    int64_t *idx_out_dev;                /* [T + 1][N][B + U] or NULL */
+    int64_t enc_rows;                    /* n_rows of the tables */
+    int32_t enc_hidden;                  /* floats per table row */
+    int32_t enc_relu6;
+} UavEnvGatedRollout;
+int uavenv_rollout_gated(uavenv_t *h, const UavEnvGatedRollout *r, const UavEnvOut *out, void *stream);
 
 /* Sticky device-side error of a handle: *code = 0, or the word a kernel left when it gave up (0x48414e44 "HAND": a wavefront of a
  * one-launch schedule waited longer than the spin budget for the wavefront that runs the first steps of the same envs -- never seen
