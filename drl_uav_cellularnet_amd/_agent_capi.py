@@ -17,8 +17,9 @@ EXPORTS = ("uavagent_abi_version", "uavagent_last_error", "uavagent_sparse_rows_
            "uavagent_relu6_bwd_workspace_bytes", "uavagent_relu6_bwd", "uavagent_rowdot_f32",
            "uavagent_rows_grad_workspace_bytes", "uavagent_rows_grad_f32", "uavagent_rows_grad_sort", "uavagent_rows_grad_sums_f32", "uavagent_nstep_returns_f32", "uavagent_rmsprop_tf1",
            "uavagent_gemm_rows_f32", "uavagent_gemm_rows_workspace_bytes", "uavagent_gemm_tn_workspace_bytes", "uavagent_gemm_tn_f32",
-           "uavagent_debug_tn_plan_check", "uavagent_actor_head_f32")
-ABI_VERSION = 4
+           "uavagent_debug_tn_plan_check", "uavagent_actor_head_f32", "uavagent_actor_head_gated_f32", "uavagent_gate_prepare",
+           "uavagent_device_error", "uavagent_device_error_clear")
+ABI_VERSION = 5
 
 _lib = None
 _P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -116,6 +117,10 @@ def load():
         "uavagent_gemm_rows_f32": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
         "uavagent_gemm_tn_f32": [_P, _P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
         "uavagent_actor_head_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I64, _P, _P],
+        "uavagent_actor_head_gated_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _I64, _P, _P, _P, C.c_uint32, _P],
+        "uavagent_gate_prepare": [],
+        "uavagent_device_error": [C.POINTER(C.c_uint32)],
+        "uavagent_device_error_clear": [],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -424,6 +429,52 @@ def actor_head(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2_out, 
                                             _ptr(h2_out), _ptr(logits_pad_out), _row_stride(logits_pad_out, "logits_pad_out"), _ptr(actions_out),
                                             _stream(h1.device))
     _check(rc, "uavagent_actor_head_f32")
+    return actions_out
+
+
+def gate_prepare():
+    """Allocates the host-mapped error word of the gated head once per process (never inside a stream capture)."""
+    _check(load().uavagent_gate_prepare(), "uavagent_gate_prepare")
+
+
+def device_error():
+    """0, or the word a gated launch left when one of its waits timed out (0x47415445 "GATE")."""
+    code = C.c_uint32(0)
+    _check(load().uavagent_device_error(C.byref(code)), "uavagent_device_error")
+    return int(code.value)
+
+
+def device_error_clear():
+    _check(load().uavagent_device_error_clear(), "uavagent_device_error_clear")
+
+
+def actor_head_gated(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2_out, logits_pad_out, actions_out, gate_obs, gate_actions,
+                     spin_us=0):
+    """uavagent_actor_head_gated_f32: the head of all T steps of a rollout in one persistent launch beside uavenv_rollout_gated
+    (BatchedMobiEnv.rollout_gated).  h1, h2_out [T, N, 200]; uniforms [T, N]; logits_pad_out [T, N, >= 640]; actions_out int64 [T, N];
+    gate_obs / gate_actions int32 [ceil(N / 16)]."""
+    for t, what in ((h1, "h1"), (w2t, "w2t"), (b2, "b2"), (w3t_padded, "w3t_padded"), (b3_padded, "b3_padded"), (uniforms, "uniforms"), (h2_out, "h2_out"),
+                    (logits_pad_out, "logits_pad_out")):
+        _f32c(t, what)
+    if h1.dim() != 3:
+        raise UavAgentError("actor_head_gated: h1 must be [T, N, H]")
+    T, N, H = h1.shape
+    nb = (N + 15) // 16
+    if tuple(w2t.shape) != (H, H) or w3t_padded.shape[1] != H or w3t_padded.shape[0] != b3_padded.numel() or tuple(h2_out.shape) != (T, N, H) or b2.numel() != H:
+        raise UavAgentError("actor_head_gated: shapes do not agree")
+    if actions_out.dtype != torch.int64 or tuple(actions_out.shape) != (T, N) or not actions_out.is_contiguous() or tuple(uniforms.shape) != (T, N):
+        raise UavAgentError("actor_head_gated: uniforms float32 [T, N] and actions_out contiguous int64 [T, N]")
+    if logits_pad_out.dim() != 3 or tuple(logits_pad_out.shape[:2]) != (T, N):
+        raise UavAgentError("actor_head_gated: logits_pad_out must be [T, N, >= 640]")
+    for g, what in ((gate_obs, "gate_obs"), (gate_actions, "gate_actions")):
+        if g.dtype != torch.int32 or tuple(g.shape) != (nb,) or not g.is_contiguous():
+            raise UavAgentError("actor_head_gated: %s must be a contiguous int32 [%d] tensor" % (what, nb))
+    _same_device("actor_head_gated", h1, w2t, b2, w3t_padded, b3_padded, uniforms, h2_out, logits_pad_out, actions_out, gate_obs, gate_actions)
+    with torch.cuda.device(h1.device):
+        rc = load().uavagent_actor_head_gated_f32(_ptr(h1), _ptr(w2t), _ptr(b2), _ptr(w3t_padded), _ptr(b3_padded), _ptr(uniforms), N, T, H,
+                                                  int(n_actions), _ptr(h2_out), _ptr(logits_pad_out), int(logits_pad_out.shape[2]),
+                                                  _ptr(actions_out), _ptr(gate_obs), _ptr(gate_actions), int(spin_us), _stream(h1.device))
+    _check(rc, "uavagent_actor_head_gated_f32")
     return actions_out
 
 

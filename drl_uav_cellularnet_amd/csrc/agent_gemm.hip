@@ -20,6 +20,8 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <string>
 #include <type_traits>
 
@@ -1162,21 +1164,22 @@ __device__ __forceinline__ void head_chunk(const float *pa, const float *pw, int
     }
 }
 
-template <int RB>
-__global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
-                                                                const float *__restrict__ w3t, const float *__restrict__ b3p,
-                                                                const float *__restrict__ uni, long long n_rows, int n_act,
-                                                                float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
-                                                                long long *__restrict__ action) {
+// One tile (16 RB rows from h1 to the action) of the head; `lds` = the workgroup's HdPlan<RB>::LdsF floats, m0 = the tile's first row.
+// COH (the gated kernel below): h1 was written by ANOTHER kernel while this one was running and the actions are read by it -- the h1 tile is
+// loaded past this CU's L1 (LDS-DMA with sc1) and the actions are stored through (agent-scope atomics).
+template <int RB, bool COH>
+__device__ __forceinline__ void actor_head_tile(float *lds, const long long m0, const float *__restrict__ h1, const float *__restrict__ w2t,
+                                                const float *__restrict__ b2, const float *__restrict__ w3t, const float *__restrict__ b3p,
+                                                const float *__restrict__ uni, long long n_rows, int n_act,
+                                                float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
+                                                long long *__restrict__ action) {
     using P = HdPlan<RB>;
     constexpr int kHdRows = P::Rows, kHdH1F4 = P::H1F4, kHdH1Pass = P::H1Pass, NCB1 = P::NCB1, NCBC = P::NCBC;
-    __shared__ __attribute__((aligned(16))) float lds[P::LdsF];
     // [h2 tile | h1 tile | ring]: the policy head (phase 2) no longer needs h1 and runs a THREE-stage ring over [h1 tile | ring]
     float *const sH2 = lds, *const sH1 = lds + kHdRows * kHdH, *const ring = lds + 2 * kHdRows * kHdH;
     float *const ring3 = sH1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4, rb = (RB == 2) ? (wave & 1) : 0, qt = (RB == 2) ? (wave >> 1) : wave;   // row block, column group
-    const long long m0 = (long long)blockIdx.x * kHdRows;
     const bool stagger_first = (wave < 4) || g_head_no_stagger;      // (waves w and w + 4 share a SIMD)
     unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hs3 = 0, hs4 = 0, hs5 = 0, hs6 = 0, hs7 = 0, hs_b = 0, hs_t = 0, hs_wait = 0, hs_first = 0;
     (void)hs0; (void)hs1; (void)hs2; (void)hs3; (void)hs4; (void)hs5; (void)hs6; (void)hs7; (void)hs_b; (void)hs_t; (void)hs_wait; (void)hs_first;
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
                 const int idx = slot * 64 + lane;
                 const float *g = (idx < lim) ? g0 + idx * 4 : g_zero16;
                 if (kHdH1F4 % 64 == 0 || idx < kHdH1F4)          // (RB = 1: the tile ends inside the last slot; the lanes beyond it would write into the ring)
-                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sH1 + slot * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)g, (lds_void_t *)(sH1 + slot * 256), 16, 0, COH ? 16 : 0);   // (aux 16 = sc1)
             }
         }
     }
@@ -1415,7 +1418,10 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
             a = fk < 0 ? first * PER + PER - 1 : first * PER + fk;
             if (a > n_act - 1) a = n_act - 1;
         }
-        if (lane == 0) action[m] = a;
+        if (lane == 0) {
+            if (COH) __hip_atomic_store(action + m, (long long)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else action[m] = a;
+        }
     }
 #ifdef UAVGEMM_STAMPS
     GEMM_STAMP(hs7);
@@ -1425,6 +1431,74 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
         d[9] = hs_wait;
     }
 #endif
+}
+
+template <int RB>
+__global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                                const float *__restrict__ w3t, const float *__restrict__ b3p,
+                                                                const float *__restrict__ uni, long long n_rows, int n_act,
+                                                                float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
+                                                                long long *__restrict__ action) {
+    __shared__ __attribute__((aligned(16))) float lds[HdPlan<RB>::LdsF];
+    actor_head_tile<RB, false>(lds, (long long)blockIdx.x * HdPlan<RB>::Rows, h1, w2t, b2, w3t, b3p, uni, n_rows, n_act, h2_out, logits, ldl, action);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The head of a WHOLE rollout as one persistent launch (uavagent_actor_head_gated_f32) beside the env library's persistent rollout kernel
+// (uavenv_rollout_gated, include/uavenv.h, which also states the protocol): a workgroup owns a PAIR of 16-row blocks for all T steps and
+// alternates between them -- while the env kernel steps and encodes one block, this kernel runs the head of the other.  Per block and step:
+// wait until gate_obs[b] >= t + 1 (h1[t] of the block's rows is in memory), one 16-row tile exactly as actor_head_kernel<1> computes it
+// (same bits), actions stored through, s_waitcnt vmcnt(0), gate_act[b] = t + 1.  No kernel boundary, graph node or host call between a
+// step's kernels any more (a2c_single_thread.py:113-118 is a loop over independent workers).  Every wait is bounded: after spin_us the
+// wave stores kGateErr in the library's host-mapped error word and leaves (uavagent_device_error).  At most 96 VGPRs
+// (amdgpu_waves_per_eu(5, 5)): two of this kernel's waves and three of the env kernel's (<= 96 VGPRs each) share a SIMD's 512.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kGateErr = 0x47415445u;      // "GATE"
+__device__ __forceinline__ bool head_gate_wait(uint32_t *word, uint32_t need, uint32_t *err, uint32_t spin_us) {
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long budget = (unsigned long long)spin_us * 100ull;           // s_memrealtime ticks at 100 MHz
+    bool ok = false;
+    for (;;) {
+        uint32_t v = 0u;
+        if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)v) >= need) { ok = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t_start > budget) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok && (threadIdx.x & 63) == 0) __hip_atomic_store(err, kGateErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("" ::: "memory");
+    return ok;
+}
+__global__ __launch_bounds__(kHdThr) __attribute__((amdgpu_waves_per_eu(5, 5))) void actor_head_gated_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                                      const float *__restrict__ w3t, const float *__restrict__ b3p,
+                                                                      const float *__restrict__ uni, long long n_rows, int n_steps, int n_act,
+                                                                      float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
+                                                                      long long *__restrict__ action, uint32_t *gate_obs, uint32_t *gate_act,
+                                                                      uint32_t *err, uint32_t spin_us) {
+    // (DYNAMIC LDS: with the 135 KB declared statically hipcc reasons that only two waves per SIMD can ever be resident, ignores
+    //  amdgpu_waves_per_eu and takes 143 VGPRs -- and then this kernel and its partner no longer fit one CU)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n_blocks = (int)((n_rows + 15) / 16), n_pairs = (n_blocks + 1) >> 1;
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        for (int t = 0; t < n_steps; ++t) {
+            const long long row0 = (long long)t * n_rows;
+            for (int half = 0; half < 2; ++half) {
+                const int blk = 2 * pair + half;
+                if (blk >= n_blocks) continue;
+                if (!head_gate_wait(gate_obs + blk, (uint32_t)t + 1u, err, spin_us)) return;
+                __syncthreads();                             // every wave has left the previous tile's LDS
+                // (the weights' base pointers pass through an empty asm: otherwise hipcc hoists the per-lane LDS-DMA source pointers of every
+                //  tile -- 40 VGPRs -- out of the step loop and, capped at 96 VGPRs, spills them)
+                const float *w2t_i = w2t, *w3t_i = w3t, *b2_i = b2, *b3p_i = b3p;
+                asm volatile("" : "+s"(w2t_i), "+s"(w3t_i), "+s"(b2_i), "+s"(b3p_i));
+                actor_head_tile<1, true>(lds, 16ll * blk, h1 + row0 * kHdH, w2t_i, b2_i, w3t_i, b3p_i, uni + row0, n_rows, n_act, h2_out + row0 * kHdH,
+                                         logits + row0 * ldl, ldl, action + row0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the actions have left
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(gate_act + blk, (uint32_t)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 #ifdef UAVGEMM_STAMPS
@@ -1676,6 +1750,54 @@ extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const 
                            b3_padded, uniforms, (long long)n_rows, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
                            reinterpret_cast<long long *>(actions_out));
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head: launch failed");
+    return UAVAGENT_OK;
+}
+
+// ---- the gated head's error word: host-mapped, one per process (allocated by uavagent_gate_prepare, never inside a launch) ----
+static uint32_t *g_gate_err_host = nullptr, *g_gate_err_dev = nullptr;
+extern "C" int uavagent_gate_prepare(void) {
+    if (g_gate_err_host != nullptr) return UAVAGENT_OK;
+    void *hp = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return fail3(UAVAGENT_E_HIP, "gate_prepare: hipHostMalloc failed");
+    std::memset(hp, 0, 64);
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return fail3(UAVAGENT_E_HIP, "gate_prepare: hipHostGetDevicePointer failed"); }
+    g_gate_err_host = static_cast<uint32_t *>(hp); g_gate_err_dev = static_cast<uint32_t *>(dp);
+    return UAVAGENT_OK;
+}
+extern "C" int uavagent_device_error(uint32_t *code) {
+    if (!code) return fail3(UAVAGENT_E_INVALID, "device_error: null pointer");
+    *code = g_gate_err_host ? *(volatile uint32_t *)g_gate_err_host : 0u;
+    return UAVAGENT_OK;
+}
+extern "C" int uavagent_device_error_clear(void) {
+    if (g_gate_err_host) *(volatile uint32_t *)g_gate_err_host = 0u;
+    return UAVAGENT_OK;
+}
+
+extern "C" int uavagent_actor_head_gated_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
+                                             const float *uniforms, int64_t n_rows, int32_t n_steps, int32_t n_hidden, int32_t n_actions,
+                                             float *h2_out, float *logits_out, int64_t ld_logits, int64_t *actions_out, uint32_t *gate_obs,
+                                             uint32_t *gate_actions, uint32_t spin_us, void *stream) {
+    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out || !gate_obs || !gate_actions)
+        return fail3(UAVAGENT_E_INVALID, "actor_head_gated: null pointer");
+    if (n_hidden != kHdH || n_actions <= 576 || n_actions > kHdNP || ld_logits < kHdNP || (ld_logits & 3) || n_rows < 1 || n_steps < 1)
+        return fail3(UAVAGENT_E_INVALID, "actor_head_gated: built for 200 hidden units and 577..640 actions, ld_logits >= 640 and a multiple of 4, "
+                                         "n_rows >= 1, n_steps >= 1");
+    if (!aligned16(h1) || !aligned16(w2t) || !aligned16(w3t_padded) || !aligned16(h2_out) || !aligned16(logits_out) || (n_rows & 3))
+        return fail3(UAVAGENT_E_INVALID, "actor_head_gated: matrices must be 16-byte aligned and n_rows a multiple of 4 (every step's block of rows "
+                                         "starts 16-byte aligned)");
+    if (g_gate_err_dev == nullptr) return fail3(UAVAGENT_E_INVALID, "actor_head_gated: call uavagent_gate_prepare() first (it allocates the error word)");
+    if (*(volatile uint32_t *)g_gate_err_host != 0u)
+        return fail3(UAVAGENT_E_DEVICE, "actor_head_gated: an earlier gated launch timed out on the device (uavagent_device_error); clear it first");
+    const long long pairs = ((n_rows + 15) / 16 + 1) / 2;
+    const unsigned grid = (unsigned)std::min<long long>(pairs, cu_count_of_current_device());
+    constexpr size_t lds_bytes = (size_t)HdPlan<1>::LdsF * sizeof(float);
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&actor_head_gated_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr_rc != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head_gated: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL(actor_head_gated_kernel, dim3(grid), dim3(kHdThr), lds_bytes, (hipStream_t)stream, h1, w2t, b2, w3t_padded, b3_padded, uniforms,
+                       (long long)n_rows, (int)n_steps, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
+                       reinterpret_cast<long long *>(actions_out), gate_obs, gate_actions, g_gate_err_dev, spin_us ? spin_us : 2000000u);
+    if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head_gated: launch failed");
     return UAVAGENT_OK;
 }
 

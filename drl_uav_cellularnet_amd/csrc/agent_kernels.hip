@@ -135,7 +135,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
-extern "C" int uavagent_abi_version(void) { return 4; }
+extern "C" int uavagent_abi_version(void) { return 5; }
 extern "C" const char *uavagent_last_error(void) { return g_err.c_str(); }
 
 extern "C" int uavagent_first_layer_f32(const float *w_a, const float *bias_a, float *out_a, const float *w_c,

@@ -17,7 +17,7 @@ namespace uavk {
 // and loads the payload coherently after it.  A wait that does not end within the budget stores kDevErrGate in the handle's error word
 // and the wavefront leaves the kernel; the host then fails every later call (UAVENV_E_DEVICE), it never hangs.
 //
-// A workgroup of 8 wavefronts owns a PAIR of blocks (32 envs) for the whole rollout and alternates between them: while the policy
+// A workgroup of 12 wavefronts owns a PAIR of blocks (32 envs) for the whole rollout and alternates between them: while the policy
 // works on one block this workgroup steps and encodes the other.  Per block and step: (1) wait for the actions; (2) the single-step body
 // of env_kernel_packed for the env-wavefronts that hold the block's envs (a wavefront that straddles the block border runs for both blocks,
 // each time with its own envs live -- uavenv_step_range's rule); (3) the observation ENCODER: per env the B + U nodes of the observation
@@ -25,12 +25,13 @@ namespace uavk {
 // optionally relu6 -- the first dense layer of main.py:147 / :153 applied to the raveled one-hot state without forming it.  One wavefront per
 // env, lane = float4 column group, UNR rows (x tables) in flight: the arithmetic and its order are those of the learner's
 // sparse_rows_sum_kernel (agent_kernels.hip), results are bit-identical; (4) publish.
-// Launch: min(pairs, CUs) workgroups, __launch_bounds__(512).  Residency: the kernel must be co-resident with its partner, so it uses
-// more than 128 VGPRs ON PURPOSE (kGateVgprFloor) and at most 168 (amdgpu_waves_per_eu(3, 3)): two of these workgroups then never fit one CU
-// (4 x 136 > 512 VGPRs per SIMD lane), and one of them fits beside one partner workgroup of 8 wavefronts x <= 88 VGPRs (2 x 168 + 2 x 88 = 512),
-// whatever order the dispatcher meets them in.
+// Launch: min(pairs, CUs) workgroups of kGateWaves = 12 wavefronts (three per SIMD).  Residency: the kernel must be co-resident with its
+// partner whatever order the dispatcher meets the two kernels in, and the register file settles that: this kernel uses at least
+// kGateVgprFloor = 88 VGPRs ON PURPOSE and at most 96 (amdgpu_waves_per_eu(5, 5)), the partner at most 96 with 8 wavefronts per workgroup.
+// Two of THESE workgroups never fit one CU (6 x 88 > 512 VGPRs per SIMD lane), two partner workgroups never do either (135 KB of LDS each),
+// and one of each always does (3 x 96 + 2 x 96 = 480): with min(pairs, CUs) workgroups of each kind every CU ends up with one pair.
 // ================================================================================================
-constexpr int kGateRows = 16, kGateWaves = 8;
+constexpr int kGateRows = 16, kGateWaves = 12;
 constexpr uint32_t kDevErrGate = 0x47415445u;      // "GATE": error word of a gate wait that timed out
 struct GatedParams {
     int T, n_blocks;
@@ -143,12 +144,12 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
     }
 }
 
-constexpr int kGateVgprFloor = 136;
+constexpr int kGateVgprFloor = 88;
 template <int BT, bool PLC, int KT, bool TWO>
-__global__ __launch_bounds__(64 * kGateWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void env_kernel_gated(char *blob, const int8_t *gid_of_u, long long N, int U, int EPW, int Gr, int B_rt,
+__global__ __launch_bounds__(64 * kGateWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void env_kernel_gated(char *blob, const int8_t *gid_of_u, long long N, int U, int EPW, int Gr, int B_rt,
                                                                      int lane_magic, const GatedParams g, const KParams p) {
     __shared__ int s_bs[kGateWaves][kMaxEpw][2 * kMaxBs];
-    asm volatile("v_mov_b32 v135, 0" ::: "v135");                    // (residency: see kGateVgprFloor above)
+    asm volatile("v_mov_b32 v87, 0" ::: "v87");                      // (residency: see kGateVgprFloor above)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_pairs = (g.n_blocks + 1) >> 1;
     OutPtrs po = p.out;

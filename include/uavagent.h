@@ -25,8 +25,9 @@ extern "C" {
 #define UAVAGENT_OK 0
 #define UAVAGENT_E_INVALID (-1)
 #define UAVAGENT_E_HIP (-3)
+#define UAVAGENT_E_DEVICE (-5)   /* a gated launch gave up on the device (uavagent_device_error) */
 
-int uavagent_abi_version(void);   /* 4 */
+int uavagent_abi_version(void);   /* 5 (5: + uavagent_actor_head_gated_f32, uavagent_gate_prepare, uavagent_device_error(_clear)) */
 const char *uavagent_last_error(void);
 
 /* out_a[m, :] = sum_k w_a[idx[m, k], :] + bias_a   (k ascending, fp32; bias added last, like embedding_bag(...) + b)
@@ -149,6 +150,24 @@ int uavagent_gemm_rows_f32(const float *a, int64_t lda, const float *w, int64_t 
 int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
                             const float *uniforms, int64_t n_rows, int32_t n_hidden, int32_t n_actions, float *h2_out, float *logits_out,
                             int64_t ld_logits, int64_t *actions_out, void *stream);
+
+/* The actor's head of a WHOLE rollout (n_steps x uavagent_actor_head_f32) as ONE persistent launch that runs beside the env library's
+ * persistent rollout kernel (uavenv_rollout_gated, include/uavenv.h -- which states the protocol): per block b of 16 consecutive rows and
+ * step t the kernel waits until gate_obs[b] >= t + 1 (h1[t] of the block is in memory), computes the block exactly as
+ * uavagent_actor_head_f32 does (bit-identical h2, logits, actions), stores the actions through and sets gate_actions[b] = t + 1.  All
+ * per-step arrays are [n_steps][n_rows][...] contiguous: h1, h2_out [T][n_rows][200], uniforms and actions_out [T][n_rows], logits_out
+ * [T][n_rows][ld_logits].  n_rows a multiple of 4.  The caller zeroes gate_actions and presets gate_obs (1 where h1[0] is ready) before the
+ * launch and launches the two kernels on DIFFERENT streams (or parallel graph branches).  min(blocks / 2, CUs) workgroups of 8 wavefronts,
+ * <= 96 VGPRs, 135 KB of LDS: one per CU, beside one workgroup of the env kernel.  Every wait is bounded (spin_us of the 100 MHz clock; 0 = 2 s):
+ * a partner that never arrives leaves 0x47415445 "GATE" in the library's error word (uavagent_device_error; uavagent_device_error_clear)
+ * and the kernel exits.  uavagent_gate_prepare() allocates that host-mapped word once per process -- call it outside any stream capture. */
+int uavagent_gate_prepare(void);
+int uavagent_device_error(uint32_t *code);
+int uavagent_device_error_clear(void);
+int uavagent_actor_head_gated_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
+                                  const float *uniforms, int64_t n_rows, int32_t n_steps, int32_t n_hidden, int32_t n_actions, float *h2_out,
+                                  float *logits_out, int64_t ld_logits, int64_t *actions_out, uint32_t *gate_obs, uint32_t *gate_actions,
+                                  uint32_t spin_us, void *stream);
 
 /* Weight gradient:  c[i, j] = sum_m a[m, i] * b[m, j]  and, when dbias_out != NULL, dbias_out[j] = sum_m b[m, j]  (the bias gradient of
  * the same layer: a column of ones rides along in the kernel).  a f32 [m_rows, n_i] CONTIGUOUS (n_i % 4 == 0, <= 200, 16-byte aligned),

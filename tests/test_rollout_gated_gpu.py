@@ -2,7 +2,7 @@
 counters.  Here the ENV side alone: the action tape is filled and every action gate opened before the launch, so the kernel runs its T steps
 without a partner -- and must leave exactly what T calls of uavenv_step + uavagent_first_layer_from_obs_f32 leave: rewards, outputs, state
 blob, index lists, encoded rows, all BIT-IDENTICAL, and the observation gates at T.  With a closed gate it must give up within its spin
-budget and poison the handle (UAVENV_E_DEVICE), never hang.  The pair of kernels is tested in tests/test_learner_kernels_gpu.py.
+budget and poison the handle (UAVENV_E_DEVICE), never hang.  Then the policy side alone (uavagent_actor_head_gated_f32), and the pair on two streams with closed gates.
 Reference: mobile_env.py:150-194 (step), :169-170 (observation planes), main.py:147,153 (first dense layer) x T, a2c_single_thread.py:113-133."""
 import numpy as np
 import pytest
@@ -127,3 +127,115 @@ def test_gated_rollout_refuses_what_it_was_not_built_for():
     env4 = _env(32, 20)
     with pytest.raises(ValueError):
         env4.rollout_gated(act, b["gate_act"][:1], b["gate_obs"], wa, None, b["out_a"])
+
+
+def _head_weights(torch, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = lambda *s: torch.rand(s, device="cuda", generator=g) * 2.0 - 1.0
+    H, NA = 200, 625
+    w2, b2, w3, b3 = rnd(H, H) * 0.2, rnd(H), rnd(H, NA) * 0.3, rnd(NA)
+    w3t, b3p = torch.zeros((640, H), device="cuda"), torch.zeros(640, device="cuda")
+    w3t[:NA], b3p[:NA] = w3.t(), b3
+    return w2.t().contiguous(), b2, w3t, b3p, NA, g
+
+
+@pytest.mark.parametrize("shape", [(64, 5), (200, 3), (52, 4), (8192, 3)], ids=lambda s: "%drows_T%d" % s)
+def test_gated_head_with_open_gates_equals_the_head_of_every_step(shape):
+    """uavagent_actor_head_gated_f32 alone: h1 of all T steps is there and every observation gate open before the launch; the persistent kernel
+    must leave the h2, logits and actions of T calls of uavagent_actor_head_f32, bit for bit, and the action gates at T."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    n, T = shape
+    w2t, b2, w3t, b3p, NA, g = _head_weights(torch, n)
+    h1 = ((torch.rand((T, n, 200), device="cuda", generator=g) * 2.0 - 1.0) * 4.0 + 2.0).clamp_(0.0, 6.0)
+    u = torch.rand((T, n), device="cuda", generator=g)
+    nb = (n + 15) // 16
+    h2, lg = torch.full((T, n, 200), float("nan"), device="cuda"), torch.full((T, n, 640), float("nan"), device="cuda")
+    act = torch.full((T, n), -1, dtype=torch.int64, device="cuda")
+    gate_obs, gate_act = torch.full((nb,), T, dtype=torch.int32, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda")
+    A.gate_prepare()
+    A.device_error_clear()
+    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act)
+    torch.cuda.synchronize()
+    assert A.device_error() == 0
+    for t in range(T):
+        h2r, lgr = torch.empty((n, 200), device="cuda"), torch.empty((n, 640), device="cuda")
+        ar = torch.empty(n, dtype=torch.int64, device="cuda")
+        A.actor_head(h1[t], w2t, b2, w3t, b3p, u[t], NA, h2r, lgr, ar)
+        assert torch.equal(h2[t], h2r) and torch.equal(lg[t], lgr) and torch.equal(act[t], ar), "step %d" % t
+    assert bool((gate_act == T).all())
+
+
+def test_gated_head_gives_up_on_a_gate_that_never_opens():
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    n, T = 64, 3
+    w2t, b2, w3t, b3p, NA, g = _head_weights(torch, 5)
+    h1 = torch.rand((T, n, 200), device="cuda", generator=g)
+    u = torch.rand((T, n), device="cuda", generator=g)
+    h2, lg = torch.empty((T, n, 200), device="cuda"), torch.empty((T, n, 640), device="cuda")
+    act = torch.empty((T, n), dtype=torch.int64, device="cuda")
+    gate_obs, gate_act = torch.ones(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda")
+    A.gate_prepare()
+    A.device_error_clear()
+    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act, spin_us=20000)
+    torch.cuda.synchronize()
+    assert A.device_error() == 0x47415445
+    assert bool((gate_act == 1).all())                               # step 0 ran
+    with pytest.raises(A.UavAgentError):
+        A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act)
+    A.device_error_clear()
+    assert A.device_error() == 0
+
+
+@pytest.mark.parametrize("shape", [(64, 20, 6), (8192, 20, 8), (200, 20, 5), (4096 + 16, 20, 4)], ids=lambda s: "%denv_%due_T%d" % s)
+def test_the_two_persistent_kernels_together_equal_the_step_by_step_rollout(shape):
+    """The pair: uavenv_rollout_gated on one stream, uavagent_actor_head_gated_f32 on another, gates closed -- each kernel waits for the other,
+    step by step and block by block.  Against the same rollout made of single launches (first layer from the observation, actor head, env step):
+    indices, first-layer rows, h2, logits, actions, rewards, env outputs and state bit for bit."""
+    torch = _torch()
+    from drl_uav_cellularnet_amd import _agent_capi as A
+
+    n, n_ue, T = shape
+    env = _env(n, n_ue)
+    ref = env.clone()
+    dev = env.device
+    hid, K = 200, env.nBS + n_ue
+    wa, ba, wc, bc = _tables(torch, env, hid, 3)
+    w2t, b2, w3t, b3p, NA, g = _head_weights(torch, n + T)
+    u = torch.rand((T, n), device=dev, generator=g)
+    b = _buffers(torch, env, T, hid)
+    h2, lg = torch.full((T, n, hid), float("nan"), device=dev), torch.full((T, n, 640), float("nan"), device=dev)
+    act = torch.full((T, n), -1, dtype=torch.int64, device=dev)
+    # slot 0: the observation the rollout starts from
+    A.first_layer_from_obs(env.observation(), env.grid_n, wa, ba, wc, bc, b["out_a"][0], b["out_c"][0], idx_out=b["idx"][0])
+    b["gate_obs"].fill_(1); b["gate_act"].zero_()
+    A.gate_prepare()
+    A.device_error_clear()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    A.actor_head_gated(b["out_a"], w2t, b2, w3t, b3p, u, NA, h2, lg, act, b["gate_obs"], b["gate_act"])
+    with torch.cuda.stream(side):
+        env.rollout_gated(act, b["gate_act"], b["gate_obs"], wa, ba, b["out_a"], wc, bc, b["out_c"], idx_out=b["idx"], reward_out=b["rew"])
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    assert A.device_error() == 0 and env.device_error() == 0
+    ea, ec = torch.empty((n, hid), device=dev), torch.empty((n, hid), device=dev)
+    ei = torch.empty((n, K), dtype=torch.int64, device=dev)
+    h2r, lgr, ar = torch.empty((n, hid), device=dev), torch.empty((n, 640), device=dev), torch.empty(n, dtype=torch.int64, device=dev)
+    for t in range(T):
+        A.first_layer_from_obs(ref.observation(), env.grid_n, wa, ba, wc, bc, ea, ec, idx_out=ei)
+        assert torch.equal(b["idx"][t], ei) and torch.equal(b["out_a"][t], ea) and torch.equal(b["out_c"][t], ec), "first layer, step %d" % t
+        A.actor_head(ea, w2t, b2, w3t, b3p, u[t], NA, h2r, lgr, ar)
+        assert torch.equal(h2[t], h2r) and torch.equal(lg[t], lgr) and torch.equal(act[t], ar), "head, step %d" % t
+        ref.step(ar)
+        assert torch.equal(b["rew"][t], ref.out["reward"]), "reward, step %d" % t
+    A.obs_indices(ref.observation(), env.grid_n, env.nBS, out=ei)
+    assert torch.equal(b["idx"][T], ei)
+    for k, v in ref.out.items():
+        if k != "reward":
+            assert torch.equal(env.out[k], v), k
+    assert np.array_equal(env.get_state(), ref.get_state())
