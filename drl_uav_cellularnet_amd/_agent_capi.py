@@ -117,7 +117,7 @@ def load():
         "uavagent_gemm_rows_f32": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
         "uavagent_gemm_tn_f32": [_P, _P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, C.c_size_t, _P],
         "uavagent_actor_head_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I64, _P, _P],
-        "uavagent_actor_head_gated_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _I64, _P, _P, _P, C.c_uint32, _P],
+        "uavagent_actor_head_gated_f32": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _I64, _P, _P, _P, _P, C.c_uint32, _P],
         "uavagent_gate_prepare": [],
         "uavagent_device_error": [C.POINTER(C.c_uint32)],
         "uavagent_device_error_clear": [],
@@ -449,10 +449,10 @@ def device_error_clear():
 
 
 def actor_head_gated(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2_out, logits_pad_out, actions_out, gate_obs, gate_actions,
-                     spin_us=0):
+                     claim, spin_us=0):
     """uavagent_actor_head_gated_f32: the head of all T steps of a rollout in one persistent launch beside uavenv_rollout_gated
     (BatchedMobiEnv.rollout_gated).  h1, h2_out [T, N, 200]; uniforms [T, N]; logits_pad_out [T, N, >= 640]; actions_out int64 [T, N];
-    gate_obs / gate_actions int32 [ceil(N / 16)]."""
+    gate_obs / gate_actions int32 [ceil(N / 16)]; claim int32 [1], zero before the launch."""
     for t, what in ((h1, "h1"), (w2t, "w2t"), (b2, "b2"), (w3t_padded, "w3t_padded"), (b3_padded, "b3_padded"), (uniforms, "uniforms"), (h2_out, "h2_out"),
                     (logits_pad_out, "logits_pad_out")):
         _f32c(t, what)
@@ -469,11 +469,13 @@ def actor_head_gated(h1, w2t, b2, w3t_padded, b3_padded, uniforms, n_actions, h2
     for g, what in ((gate_obs, "gate_obs"), (gate_actions, "gate_actions")):
         if g.dtype != torch.int32 or tuple(g.shape) != (nb,) or not g.is_contiguous():
             raise UavAgentError("actor_head_gated: %s must be a contiguous int32 [%d] tensor" % (what, nb))
-    _same_device("actor_head_gated", h1, w2t, b2, w3t_padded, b3_padded, uniforms, h2_out, logits_pad_out, actions_out, gate_obs, gate_actions)
+    if claim.dtype != torch.int32 or claim.numel() != 1:
+        raise UavAgentError("actor_head_gated: claim must be an int32 [1] tensor")
+    _same_device("actor_head_gated", h1, w2t, b2, w3t_padded, b3_padded, uniforms, h2_out, logits_pad_out, actions_out, gate_obs, gate_actions, claim)
     with torch.cuda.device(h1.device):
         rc = load().uavagent_actor_head_gated_f32(_ptr(h1), _ptr(w2t), _ptr(b2), _ptr(w3t_padded), _ptr(b3_padded), _ptr(uniforms), N, T, H,
                                                   int(n_actions), _ptr(h2_out), _ptr(logits_pad_out), int(logits_pad_out.shape[2]),
-                                                  _ptr(actions_out), _ptr(gate_obs), _ptr(gate_actions), int(spin_us), _stream(h1.device))
+                                                  _ptr(actions_out), _ptr(gate_obs), _ptr(gate_actions), _ptr(claim), int(spin_us), _stream(h1.device))
     _check(rc, "uavagent_actor_head_gated_f32")
     return actions_out
 

@@ -43,7 +43,7 @@ class UavEnvOut(C.Structure):
 
 
 class UavEnvGatedRollout(C.Structure):      # include/uavenv.h
-    _fields_ = [("n_steps", C.c_int32), ("actions_dev", C.c_void_p), ("gate_actions_dev", C.c_void_p), ("gate_obs_dev", C.c_void_p),
+    _fields_ = [("n_steps", C.c_int32), ("actions_dev", C.c_void_p), ("gate_actions_dev", C.c_void_p), ("gate_obs_dev", C.c_void_p), ("claim_dev", C.c_void_p),
                 ("reward_dev", C.c_void_p), ("enc_table_a_dev", C.c_void_p), ("enc_bias_a_dev", C.c_void_p), ("enc_out_a_dev", C.c_void_p),
                 ("enc_table_c_dev", C.c_void_p), ("enc_bias_c_dev", C.c_void_p), ("enc_out_c_dev", C.c_void_p), ("idx_out_dev", C.c_void_p),
                 ("enc_rows", C.c_int64), ("enc_hidden", C.c_int32), ("enc_relu6", C.c_int32)]

@@ -330,7 +330,8 @@ class A2CRunner:
 
     def __init__(self, env, net=None, rollout=50, gamma=GAMMA, beta=ENTROPY_BETA, lr_a=LR_A, lr_c=LR_C, seed=6,
                  update_chunk=65536, first_state="obs", collect_launch="graph", fused_update=True, tune_gemms=False, hip_gemms=True,
-                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=True, force_exchange=False):
+                 overlap_allreduce=True, fused_head=True, overlap_dw=False, fused_obs=True, early_sort=True, pipeline_halves=True, force_exchange=False,
+                 persistent_rollout="auto"):
         self.env = env
         self.dev = env.device
         self.gemm_tuning = enable_gemm_tuning() if (tune_gemms and self.dev.type == "cuda") else False
@@ -396,6 +397,17 @@ class A2CRunner:
             cuts = [min(i * per, env.n_envs) for i in range(n_parts)] + [env.n_envs]
             if all(cuts[i] < cuts[i + 1] for i in range(n_parts)) and (pipeline_halves == "force" or env.n_envs >= 4096):
                 self._halves = tuple((cuts[i], cuts[i + 1]) for i in range(n_parts))
+        # persistent_rollout (GPU, fused_head + fused_obs, the reference's 4 UAVs and <= 64 UEs): the whole rollout as TWO persistent kernel
+        # launches on two streams -- uavagent_actor_head_gated_f32 (the policy) and uavenv_rollout_gated (env step + next observation's first
+        # layer) -- that hand 16-env blocks to each other through step counters in device memory (include/uavenv.h has the protocol): no kernel
+        # boundary, graph node or cross-stream edge per step any more; each CU hosts one workgroup of either kernel and ping-pongs between the
+        # two blocks of its pair.  Same arithmetic per env and step: bit-identical to the other forms.  Every device-side wait is bounded; a
+        # timeout surfaces as RuntimeError from collect().  "auto" = from 4096 envs on; True = whenever the shapes allow (tests); the first
+        # collect() proves on a CLONE of the env state that the two kernels do run side by side, and falls back to pipeline_halves if not.
+        self._persistent = False
+        if (persistent_rollout and self.dev.type == "cuda" and self.fused_head and self.fused_obs and env.nBS == 4 and env.nUE <= 64
+                and env.n_envs % 4 == 0 and (persistent_rollout is True or env.n_envs >= 4096)):
+            self._persistent = True
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
         # idx_buf[T] = the state the rollout ended in (bootstrap value; copied to slot 0 when the next rollout starts).
@@ -421,6 +433,14 @@ class A2CRunner:
             self._wt = {"a_w2t": f(H, H), "c_w2t": f(H, H), "a_w3t": torch.zeros((self._ldl, H), dtype=torch.float32, device=self.dev),
                         "a_b3p": torch.zeros(self._ldl, dtype=torch.float32, device=self.dev)} if self.hip_gemms else None
         self._fwd_valid = False
+        if self._persistent:
+            nb = (N + 15) // 16
+            self._gate_obs = torch.zeros(nb, dtype=torch.int32, device=self.dev)
+            self._gate_act = torch.zeros(nb, dtype=torch.int32, device=self.dev)
+            self._gate_claim = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            from . import _agent_capi as _A
+
+            _A.gate_prepare()
         # first_state: "obs" = the observation the constructor's channel update produced; "zeros" = what the reference's first
         # work() call sees, the all-zero env.state of a never-reset env (a2c_single_thread.py:143,155): no non-zero cell, i.e.
         # every index is -1 = "no row" and the first layer returns its bias.
@@ -457,6 +477,8 @@ class A2CRunner:
     def _rollout_steps(self):
         """The T-step loop: choose_action (main.py:165-169) -> env.step -> next observation.  No host synchronisation, no
         allocation visible to the caller: capturable."""
+        if self._persistent:
+            return self._rollout_steps_persistent()
         if self._halves is not None:
             return self._rollout_steps_pipelined()
         env, T, net = self.env, self.T, self.net
@@ -495,6 +517,39 @@ class A2CRunner:
             env.step(self.act_buf[t], reward_out=self.rew_buf[t])
             if not fused_obs or t == T - 1:
                 self._indices_into(self.idx_buf[t + 1])
+
+    def _rollout_steps_persistent(self):
+        """The T-step loop as two persistent launches (see persistent_rollout in __init__): the first layer of the state the rollout starts
+        from, the gates, then the policy kernel on the calling stream and the env kernel on a side stream.  Capturable."""
+        from . import _agent_capi as A
+
+        env, T, net, fw, wt = self.env, self.T, self.net, self._fwd, self._wt
+        self.idx_buf[0].copy_(self.idx_buf[T])
+        A.sparse_rows_sum(self.idx_buf[0], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][0], out_c=fw["h1c"][0])
+        self._gate_obs.fill_(1)
+        self._gate_act.zero_()
+        self._gate_claim.zero_()
+        main = torch.cuda.current_stream(self.dev)
+        if not self._pipe_streams:
+            self._pipe_streams.append(torch.cuda.Stream(device=self.dev))
+        side = self._pipe_streams[0]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        A.actor_head_gated(fw["h1a"], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf, net.n_action, fw["h2a"], self._logits_pad, self.act_buf,
+                           self._gate_obs, self._gate_act, self._gate_claim[1:2])
+        with torch.cuda.stream(side):
+            env.rollout_gated(self.act_buf, self._gate_act, self._gate_obs, self._gate_claim[0:1], net.a_w1, net.a_b1, fw["h1a"], net.c_w1, net.c_b1, fw["h1c"],
+                              idx_out=self.idx_buf, reward_out=self.rew_buf)
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
+
+    def _persistent_failed(self):
+        """True when a gated launch gave up on the device (both libraries keep a sticky word in host-mapped memory)."""
+        from . import _agent_capi as A
+
+        return A.device_error() != 0 or self.env.device_error() != 0
 
     def _rollout_steps_pipelined(self):
         """The T-step loop with the batch cut in parts, one stream each (see pipeline_halves in __init__).  Per part and step: first
@@ -570,9 +625,17 @@ class A2CRunner:
         self._fwd_valid = self._fwd is not None
         self.ep_r += self.rew_buf.sum(dim=0)
         done = env.out["done"].bool()
+        persistent_ran = self._persistent
         boot = self.net.critic_only(self.idx_buf[T]).squeeze(1)                      # :173-176
         boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
-        if bool(done.any()):                                                         # :167-172 reset_worker
+        any_done = bool(done.any())                                                  # (host sync: the rollout's kernels have finished)
+        if persistent_ran and self._persistent_failed():
+            from . import _agent_capi as _A2
+
+            raise RuntimeError("A2CRunner.collect: a persistent rollout kernel gave up waiting for its partner (device error words: policy 0x%08x, "
+                               "env 0x%08x); the env state is incomplete -- set_state() / load_state_dict() before going on"
+                               % (_A2.device_error(), env.device_error()))
+        if any_done:                                                                 # :167-172 reset_worker
             m = float(self.ep_r[done].mean())
             self.last_episode_return = m                                             # mean return of the episodes that just ended
             self.running_r = m if self.running_r is None else 0.99 * self.running_r + 0.01 * m
@@ -600,22 +663,48 @@ class A2CRunner:
         env.copy_state_to(state)
         keep = {k: v.clone() for k, v in env.out.items()}
         keep_idx = self.idx_buf[self.T].clone()
+        def restore():
+            env.copy_state_from(state)                 # (also clears the env handle's device-error word)
+            for k, v in keep.items():
+                env.out[k].copy_(v)
+            self.idx_buf[self.T].copy_(keep_idx)
+
+        def give_up_persistent(where):
+            import warnings
+            from . import _agent_capi as A
+
+            warnings.warn("A2CRunner: the persistent rollout kernels did not run side by side (%s: a gate wait timed out); using the "
+                          "per-step launches instead" % where)
+            self._persistent = False
+            A.device_error_clear()
+            restore()
+
         s = torch.cuda.Stream(device=self.dev)
-        s.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(s):
-            self._rollout_steps()
-        torch.cuda.current_stream(self.dev).wait_stream(s)
-        torch.cuda.synchronize(self.dev)
-        env.copy_state_from(state)
-        for k, v in keep.items():
-            env.out[k].copy_(v)
-        self.idx_buf[self.T].copy_(keep_idx)
-        # capture_error_mode="thread_local": with torch.distributed initialised, RCCL's watchdog thread polls events while this
-        # thread captures; in the default "global" mode that invalidates the capture.
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self._rollout_steps()
-        self._graph = g
+        for attempt in range(2):
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                self._rollout_steps()
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            torch.cuda.synchronize(self.dev)
+            if self._persistent and self._persistent_failed():
+                give_up_persistent("eager warm-up pass")
+                continue
+            restore()
+            # capture_error_mode="thread_local": with torch.distributed initialised, RCCL's watchdog thread polls events while this
+            # thread captures; in the default "global" mode that invalidates the capture.
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._rollout_steps()
+            if self._persistent:
+                # a graph's parallel branches need not run at the same time; the two persistent kernels must: one trial replay on the clone
+                g.replay()
+                torch.cuda.synchronize(self.dev)
+                if self._persistent_failed():
+                    give_up_persistent("trial replay of the captured graph")
+                    continue
+                restore()
+            self._graph = g
+            return
 
     # ---- update ----------------------------------------------------------------------------------------------------
     def update(self, idx_buf, act_buf, rew_buf, boot):

@@ -245,11 +245,11 @@ class BatchedMobiEnv:
 
     GATE_ROWS = 16          # UAVENV_GATE_ROWS: envs per gate word of rollout_gated
 
-    def rollout_gated(self, actions, gate_actions, gate_obs, table_a, bias_a, out_a, table_c=None, bias_c=None, out_c=None, idx_out=None,
+    def rollout_gated(self, actions, gate_actions, gate_obs, claim, table_a, bias_a, out_a, table_c=None, bias_c=None, out_c=None, idx_out=None,
                       reward_out=None, relu6=True):
         """uavenv_rollout_gated: T = len(actions) steps in ONE persistent launch that takes its actions from a policy kernel running
         beside it on another stream (include/uavenv.h has the protocol).  ``actions`` int64 [T, N] (written by the policy while this
-        launch runs), ``gate_actions`` / ``gate_obs`` int32 [ceil(N / 16)] step counters, tables float32 [n_rows, hidden], outputs
+        launch runs), ``gate_actions`` / ``gate_obs`` int32 [ceil(N / 16)] step counters, ``claim`` int32 [1] (zero before the launch), tables float32 [n_rows, hidden], outputs
         float32 [T, N, hidden] (slot t + 1 written after step t), ``idx_out`` int64 [T + 1, N, B + U], ``reward_out`` float32 [T, N].
         Asynchronous; a partner that never arrives ends in device_error() != 0, not in a hang."""
         T, N = int(actions.shape[0]), self.n_envs
@@ -261,6 +261,7 @@ class BatchedMobiEnv:
         chk(actions, torch.int64, (T, N), "actions")
         chk(gate_actions, torch.int32, (nb,), "gate_actions")
         chk(gate_obs, torch.int32, (nb,), "gate_obs")
+        chk(claim, torch.int32, (1,), "claim")
         rows, hid = int(table_a.shape[0]), int(table_a.shape[1])
         chk(table_a, torch.float32, (rows, hid), "table_a")
         chk(out_a, torch.float32, (T, N, hid), "out_a")
@@ -277,7 +278,7 @@ class BatchedMobiEnv:
             chk(reward_out, torch.float32, (T, N), "reward_out")
         r = _capi.UavEnvGatedRollout()
         r.n_steps = T
-        r.actions_dev, r.gate_actions_dev, r.gate_obs_dev = actions.data_ptr(), gate_actions.data_ptr(), gate_obs.data_ptr()
+        r.actions_dev, r.gate_actions_dev, r.gate_obs_dev, r.claim_dev = actions.data_ptr(), gate_actions.data_ptr(), gate_obs.data_ptr(), claim.data_ptr()
         r.reward_dev = reward_out.data_ptr() if reward_out is not None else None
         r.enc_table_a_dev, r.enc_out_a_dev = table_a.data_ptr(), out_a.data_ptr()
         r.enc_bias_a_dev = bias_a.data_ptr() if bias_a is not None else None

@@ -1450,10 +1450,16 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
 // wait until gate_obs[b] >= t + 1 (h1[t] of the block's rows is in memory), one 16-row tile exactly as actor_head_kernel<1> computes it
 // (same bits), actions stored through, s_waitcnt vmcnt(0), gate_act[b] = t + 1.  No kernel boundary, graph node or host call between a
 // step's kernels any more (a2c_single_thread.py:113-118 is a loop over independent workers).  Every wait is bounded: after spin_us the
-// wave stores kGateErr in the library's host-mapped error word and leaves (uavagent_device_error).  At most 96 VGPRs
-// (amdgpu_waves_per_eu(5, 5)): two of this kernel's waves and three of the env kernel's (<= 96 VGPRs each) share a SIMD's 512.
+// wave stores kGateErr in the library's host-mapped error word and leaves (uavagent_device_error).  At most 128 VGPRs
+// (amdgpu_waves_per_eu(4, 4)): two of this kernel's waves and two of the env kernel's (<= 128 VGPRs each) share a SIMD's 512.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kGateErr = 0x47415445u;      // "GATE"
+#ifdef UAVAGENT_GATE_STAMPS     /* diagnostic build (tools/gated_timeline.py): s_memrealtime of pair 0's events, same buffer as the env kernel's stamps */
+__device__ unsigned long long *g_hgate_dbg;   // [T][2 halves][8]: slot 0 = h1 seen, 1 = actions published
+#define HGATE_STAMP(t, half, k) do { if (g_hgate_dbg != nullptr && pair == 0 && threadIdx.x == 0) g_hgate_dbg[((t) * 2 + (half)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HGATE_STAMP(t, half, k) do { } while (0)
+#endif
 __device__ __forceinline__ bool head_gate_wait(uint32_t *word, uint32_t need, uint32_t *err, uint32_t spin_us) {
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     const unsigned long long budget = (unsigned long long)spin_us * 100ull;           // s_memrealtime ticks at 100 MHz
@@ -1469,23 +1475,35 @@ __device__ __forceinline__ bool head_gate_wait(uint32_t *word, uint32_t need, ui
     asm volatile("" ::: "memory");
     return ok;
 }
-__global__ __launch_bounds__(kHdThr) __attribute__((amdgpu_waves_per_eu(5, 5))) void actor_head_gated_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
+#ifdef UAVAGENT_GATE_NOCAP      /* timing experiment: what the 96-VGPR cap costs (this build cannot run beside its partner) */
+#define UAVAGENT_GATE_CAP
+#else
+#define UAVAGENT_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+__global__ __launch_bounds__(kHdThr) UAVAGENT_GATE_CAP void actor_head_gated_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
                                                                       const float *__restrict__ w3t, const float *__restrict__ b3p,
                                                                       const float *__restrict__ uni, long long n_rows, int n_steps, int n_act,
                                                                       float *__restrict__ h2_out, float *__restrict__ logits, long long ldl,
                                                                       long long *__restrict__ action, uint32_t *gate_obs, uint32_t *gate_act,
-                                                                      uint32_t *err, uint32_t spin_us) {
+                                                                      uint32_t *claim, uint32_t *err, uint32_t spin_us) {
     // (DYNAMIC LDS: with the 135 KB declared statically hipcc reasons that only two waves per SIMD can ever be resident, ignores
-    //  amdgpu_waves_per_eu and takes 143 VGPRs -- and then this kernel and its partner no longer fit one CU)
+    //  amdgpu_waves_per_eu and takes 143 VGPRs -- and then this kernel and its partner no longer fit one CU: 2 x 128 + 2 x 128)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n_blocks = (int)((n_rows + 15) / 16), n_pairs = (n_blocks + 1) >> 1;
-    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    __shared__ int s_pair;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_pair = (int)atomicAdd(claim, 1u);      // pairs are claimed in arrival order (uavenv_gated_kernel.h: "Residency")
+        __syncthreads();
+        const int pair = s_pair;
+        if (pair >= n_pairs) break;
         for (int t = 0; t < n_steps; ++t) {
             const long long row0 = (long long)t * n_rows;
             for (int half = 0; half < 2; ++half) {
                 const int blk = 2 * pair + half;
                 if (blk >= n_blocks) continue;
                 if (!head_gate_wait(gate_obs + blk, (uint32_t)t + 1u, err, spin_us)) return;
+                HGATE_STAMP(t, half, 0);
                 __syncthreads();                             // every wave has left the previous tile's LDS
                 // (the weights' base pointers pass through an empty asm: otherwise hipcc hoists the per-lane LDS-DMA source pointers of every
                 //  tile -- 40 VGPRs -- out of the step loop and, capped at 96 VGPRs, spills them)
@@ -1496,6 +1514,7 @@ __global__ __launch_bounds__(kHdThr) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the actions have left
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(gate_act + blk, (uint32_t)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                HGATE_STAMP(t, half, 1);
             }
         }
     }
@@ -1753,6 +1772,12 @@ extern "C" int uavagent_actor_head_f32(const float *h1, const float *w2t, const 
     return UAVAGENT_OK;
 }
 
+#ifdef UAVAGENT_GATE_STAMPS
+extern "C" int uavagent_debug_set_gate_stamps(void *dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_hgate_dbg), &dev_ptr, sizeof(void *)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ---- the gated head's error word: host-mapped, one per process (allocated by uavagent_gate_prepare, never inside a launch) ----
 static uint32_t *g_gate_err_host = nullptr, *g_gate_err_dev = nullptr;
 extern "C" int uavagent_gate_prepare(void) {
@@ -1777,8 +1802,8 @@ extern "C" int uavagent_device_error_clear(void) {
 extern "C" int uavagent_actor_head_gated_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
                                              const float *uniforms, int64_t n_rows, int32_t n_steps, int32_t n_hidden, int32_t n_actions,
                                              float *h2_out, float *logits_out, int64_t ld_logits, int64_t *actions_out, uint32_t *gate_obs,
-                                             uint32_t *gate_actions, uint32_t spin_us, void *stream) {
-    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out || !gate_obs || !gate_actions)
+                                             uint32_t *gate_actions, uint32_t *claim, uint32_t spin_us, void *stream) {
+    if (!h1 || !w2t || !b2 || !w3t_padded || !b3_padded || !uniforms || !h2_out || !logits_out || !actions_out || !gate_obs || !gate_actions || !claim)
         return fail3(UAVAGENT_E_INVALID, "actor_head_gated: null pointer");
     if (n_hidden != kHdH || n_actions <= 576 || n_actions > kHdNP || ld_logits < kHdNP || (ld_logits & 3) || n_rows < 1 || n_steps < 1)
         return fail3(UAVAGENT_E_INVALID, "actor_head_gated: built for 200 hidden units and 577..640 actions, ld_logits >= 640 and a multiple of 4, "
@@ -1796,7 +1821,7 @@ extern "C" int uavagent_actor_head_gated_f32(const float *h1, const float *w2t, 
     if (attr_rc != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head_gated: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipLaunchKernelGGL(actor_head_gated_kernel, dim3(grid), dim3(kHdThr), lds_bytes, (hipStream_t)stream, h1, w2t, b2, w3t_padded, b3_padded, uniforms,
                        (long long)n_rows, (int)n_steps, (int)n_actions, h2_out, logits_out, (long long)ld_logits,
-                       reinterpret_cast<long long *>(actions_out), gate_obs, gate_actions, g_gate_err_dev, spin_us ? spin_us : 2000000u);
+                       reinterpret_cast<long long *>(actions_out), gate_obs, gate_actions, claim, g_gate_err_dev, spin_us ? spin_us : 2000000u);
     if (hipGetLastError() != hipSuccess) return fail3(UAVAGENT_E_HIP, "actor_head_gated: launch failed");
     return UAVAGENT_OK;
 }

@@ -13,8 +13,8 @@ using uavenv_internal::call_is_fast;
 
 extern "C" int uavenv_rollout_gated(uavenv_t *h, const UavEnvGatedRollout *r, const UavEnvOut *out, void *stream) {
     if (!h || !r || !out) return fail(UAVENV_E_INVALID, "rollout_gated: null handle, description or outputs");
-    if (r->n_steps < 1 || !r->actions_dev || !r->gate_actions_dev || !r->gate_obs_dev || !r->enc_table_a_dev || !r->enc_out_a_dev)
-        return fail(UAVENV_E_INVALID, "rollout_gated: n_steps >= 1, the action tape, both gate arrays, table a and its output are required");
+    if (r->n_steps < 1 || !r->actions_dev || !r->gate_actions_dev || !r->gate_obs_dev || !r->claim_dev || !r->enc_table_a_dev || !r->enc_out_a_dev)
+        return fail(UAVENV_E_INVALID, "rollout_gated: n_steps >= 1, the action tape, both gate arrays, the claim word, table a and its output are required");
     if ((r->enc_table_c_dev != nullptr) != (r->enc_out_c_dev != nullptr)) return fail(UAVENV_E_INVALID, "rollout_gated: table c and its output come together");
     if (!h->packed || h->bt != 4 || h->kp.B != 4 || h->N > 0x7FFFFFFFll)
         return fail(UAVENV_E_INVALID, "rollout_gated: built for n_ue <= 64 and n_bs == 4");
@@ -33,7 +33,7 @@ extern "C" int uavenv_rollout_gated(uavenv_t *h, const UavEnvGatedRollout *r, co
     p.n_ticks = 1;
     GatedParams g;
     g.T = r->n_steps; g.n_blocks = (int)((h->N + kGateRows - 1) / kGateRows);
-    g.actions = (const long long *)r->actions_dev; g.gate_act = r->gate_actions_dev; g.gate_obs = r->gate_obs_dev; g.reward = r->reward_dev;
+    g.actions = (const long long *)r->actions_dev; g.gate_act = r->gate_actions_dev; g.gate_obs = r->gate_obs_dev; g.claim = r->claim_dev; g.reward = r->reward_dev;
     g.wa = r->enc_table_a_dev; g.ba = r->enc_bias_a_dev; g.wc = r->enc_table_c_dev; g.bc = r->enc_bias_c_dev;
     g.oa = r->enc_out_a_dev; g.oc = r->enc_out_c_dev; g.idx_out = (long long *)r->idx_out_dev;
     g.n_rows = r->enc_rows; g.H4 = r->enc_hidden / 4; g.relu6 = r->enc_relu6; g.G = p.G;
@@ -57,3 +57,9 @@ extern "C" int uavenv_rollout_gated(uavenv_t *h, const UavEnvGatedRollout *r, co
     return UAVENV_OK;
 }
 
+
+#ifdef UAVENV_GATE_STAMPS
+extern "C" int uavenv_debug_set_gate_stamps(void *dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(uavk::g_gate_dbg), &dev_ptr, sizeof(void *)) == hipSuccess ? 0 : -1;
+}
+#endif

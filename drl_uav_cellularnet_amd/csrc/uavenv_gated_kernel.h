@@ -17,7 +17,7 @@ namespace uavk {
 // and loads the payload coherently after it.  A wait that does not end within the budget stores kDevErrGate in the handle's error word
 // and the wavefront leaves the kernel; the host then fails every later call (UAVENV_E_DEVICE), it never hangs.
 //
-// A workgroup of 12 wavefronts owns a PAIR of blocks (32 envs) for the whole rollout and alternates between them: while the policy
+// A workgroup of 8 wavefronts owns a PAIR of blocks (32 envs) for the whole rollout and alternates between them: while the policy
 // works on one block this workgroup steps and encodes the other.  Per block and step: (1) wait for the actions; (2) the single-step body
 // of env_kernel_packed for the env-wavefronts that hold the block's envs (a wavefront that straddles the block border runs for both blocks,
 // each time with its own envs live -- uavenv_step_range's rule); (3) the observation ENCODER: per env the B + U nodes of the observation
@@ -25,18 +25,43 @@ namespace uavk {
 // optionally relu6 -- the first dense layer of main.py:147 / :153 applied to the raveled one-hot state without forming it.  One wavefront per
 // env, lane = float4 column group, UNR rows (x tables) in flight: the arithmetic and its order are those of the learner's
 // sparse_rows_sum_kernel (agent_kernels.hip), results are bit-identical; (4) publish.
-// Launch: min(pairs, CUs) workgroups of kGateWaves = 12 wavefronts (three per SIMD).  Residency: the kernel must be co-resident with its
-// partner whatever order the dispatcher meets the two kernels in, and the register file settles that: this kernel uses at least
-// kGateVgprFloor = 88 VGPRs ON PURPOSE and at most 96 (amdgpu_waves_per_eu(5, 5)), the partner at most 96 with 8 wavefronts per workgroup.
-// Two of THESE workgroups never fit one CU (6 x 88 > 512 VGPRs per SIMD lane), two partner workgroups never do either (135 KB of LDS each),
-// and one of each always does (3 x 96 + 2 x 96 = 480): with min(pairs, CUs) workgroups of each kind every CU ends up with one pair.
+// (Tried and not kept, all bit-identical, profiles/r04g_*: four wavefronts stepping while four encode, counters in LDS between them -- a step
+// of the pair took 84 us instead of 76: half the wavefronts have half the row pieces in flight; one wavefront per (env, table) with all 24 pieces
+// issued at once: the same time as 16 at once; every second pair starting 8-36 us late so that the CUs' encoder phases do not coincide: 1 %;
+// non-temporal table loads: the encoder alone 4.19 instead of 3.13 ms per rollout.)
+// Launch: min(pairs, CUs) workgroups of kGateWaves = 8 wavefronts, at most 128 VGPRs (amdgpu_waves_per_eu(4, 4)); the partner the same: one
+// workgroup of each fills a CU's register file exactly (2 x 128 + 2 x 128 per SIMD lane), and that is how an idle chip is filled -- one pair per
+// CU.  Residency: nothing here DEPENDS on that placement.  Pairs of blocks are claimed from a counter in arrival order by both kernels, so
+// whichever workgroups are resident hold the lowest unfinished pairs on both sides; if the dispatcher ever puts two of these workgroups on one
+// CU (and the partner's therefore on none), the pairs left over simply start when a workgroup has finished its rollout -- slower, never stuck.
+// (A first version assigned pairs by workgroup index and kept two of its workgroups off one CU by using 88..96 VGPRs on purpose, 12
+// wavefronts; at 96 VGPRs both kernels spilled: this kernel alone 3.12 against 2.47 ms per 8192 x 50 rollout, the partner 2.89 against 1.96,
+// profiles/r04g_gated_kernels_alone_vgpr_caps.txt.)
 // ================================================================================================
-constexpr int kGateRows = 16, kGateWaves = 12;
+constexpr int kGateRows = 16, kGateWaves = 8;
+// What the step body loads coherently (env_packed_body's HO bits): the ACTIONS -- another kernel wrote them.  Not the env state and not the
+// observation the encoder reads back: only wavefronts of this workgroup touch them during the launch, they share one CU and its L1 (work-group
+// scope needs no cache bypass on gfx950), and the launch boundary took care of everything older.  UAVENV_GATE_COHERENT_STATE=1 (build flag,
+// A/B): state and observation past the L1 as well.
+#ifdef UAVENV_GATE_COHERENT_STATE
+constexpr int kGateHO = 5;
+#define GATE_OBS_LOAD(ptr) __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+constexpr int kGateHO = 4;
+#define GATE_OBS_LOAD(ptr) (*(ptr))
+#endif
+#ifdef UAVENV_GATE_STAMPS       /* diagnostic build (tools/gated_timeline.py): s_memrealtime (100 MHz, one clock for the whole chip) of pair 0's events */
+__device__ unsigned long long *g_gate_dbg;    // [T][2 halves][8]: slot 2 = actions seen, 3 = env step done (outputs in L2), 4 = encoded rows published
+#define GATE_STAMP(t, half, k) do { if (g_gate_dbg != nullptr && pair == 0 && threadIdx.x == 0) g_gate_dbg[((t) * 2 + (half)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GATE_STAMP(t, half, k) do { } while (0)
+#endif
 constexpr uint32_t kDevErrGate = 0x47415445u;      // "GATE": error word of a gate wait that timed out
 struct GatedParams {
     int T, n_blocks;
     const long long *actions;      // [T][N]
     uint32_t *gate_act, *gate_obs; // [n_blocks]
+    uint32_t *claim;               // one word, zero before the launch: the next pair of blocks nobody has taken yet
     float *reward;                 // [T][N] or null (then p.out.reward is overwritten every step like every other output)
     const float *wa, *ba, *wc, *bc;// tables [n_rows][4 H4] and biases [4 H4] (wc / bc null: one table)
     float *oa, *oc;                // [T][N][4 H4]: slot t + 1 is written after step t (t + 1 < T)
@@ -75,6 +100,21 @@ __device__ __forceinline__ void enc_store4(float *dst, const float4 &v) {      /
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst) + 1, u.w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A table row piece.  UAVENV_GATE_NT (build flag, A/B): as a non-temporal load, so that the 20 MB per XCD and block-step the encoder streams
+// through the L2 do not evict the 672 KB of weights the partner kernel's workgroups keep re-reading from it.
+__device__ __forceinline__ float4 enc_load4(const char *q) {
+#if defined(UAVENV_GATE_SKIP) && UAVENV_GATE_SKIP == 1
+    return float4{1.f, 2.f, 3.f, 4.f};
+#endif
+#ifdef UAVENV_GATE_NT
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(q));
+    return float4{v.x, v.y, v.z, v.w};
+#else
+    return *reinterpret_cast<const float4 *>(q);
+#endif
+}
+
 // The encoder for env m (one wavefront).  KT > 0: B + U known at compile time (the row loop unrolls by UNR around v_readlane).
 template <int KT, int UNR, bool TWO>
 __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &obs, long long m, int U, int B, long long N, int t_slot, bool gather) {
@@ -83,16 +123,16 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
     long long mine = 0;
     if (lane < K) {
         int x, y, pl;
-        if (lane < B) {     // coherent loads: these words were written by other wavefronts of this workgroup a moment ago (past this CU's L1)
+        if (lane < B) {     // (written by other wavefronts of this workgroup a moment ago: see kGateHO)
             union { unsigned long long w; int2 c; } q;
-            q.w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(obs.bs_xy) + (m * B + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.w = GATE_OBS_LOAD(reinterpret_cast<const unsigned long long *>(obs.bs_xy) + (m * B + lane));
             x = q.c.x; y = q.c.y; pl = 0;
         } else {
             const long long iu = m * U + (lane - B);
             union { uint32_t w; short2 c; } q;
-            q.w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(obs.ue_xy) + iu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.w = GATE_OBS_LOAD(reinterpret_cast<const uint32_t *>(obs.ue_xy) + iu);
             x = q.c.x; y = q.c.y;
-            pl = 1 + (int)__hip_atomic_load(obs.serving + iu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pl = 1 + (int)GATE_OBS_LOAD(obs.serving + iu);
         }
         const bool ok = x >= 0 && x < g.G && y >= 0 && y < g.G && pl >= 0 && pl <= B;
         mine = ok ? ((long long)pl * g.G + x) * g.G + y : -1ll;
@@ -144,16 +184,27 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
     }
 }
 
-constexpr int kGateVgprFloor = 88;
+#ifdef UAVENV_GATE_NOCAP        /* timing experiment: what the 96-VGPR cap costs (this build cannot run beside its partner) */
+#define UAVENV_GATE_CAP
+#else
+#define UAVENV_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <int BT, bool PLC, int KT, bool TWO>
-__global__ __launch_bounds__(64 * kGateWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void env_kernel_gated(char *blob, const int8_t *gid_of_u, long long N, int U, int EPW, int Gr, int B_rt,
-                                                                     int lane_magic, const GatedParams g, const KParams p) {
+__global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_gated(char *blob, const int8_t *gid_of_u, long long N, int U, int EPW, int Gr, int B_rt,
+                                                                                     int lane_magic, const GatedParams g, const KParams p) {
     __shared__ int s_bs[kGateWaves][kMaxEpw][2 * kMaxBs];
-    asm volatile("v_mov_b32 v87, 0" ::: "v87");                      // (residency: see kGateVgprFloor above)
+    __shared__ int s_pair;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_pairs = (g.n_blocks + 1) >> 1;
     OutPtrs po = p.out;
-    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    for (;;) {
+        // pairs are CLAIMED, not assigned by workgroup index: the p-th workgroup of this kernel to arrive works with the p-th of the partner
+        // kernel, so the lowest unfinished pairs are always held by resident workgroups on both sides (see "Residency" above)
+        __syncthreads();
+        if (threadIdx.x == 0) s_pair = (int)atomicAdd(g.claim, 1u);
+        __syncthreads();
+        const int pair = s_pair;
+        if (pair >= n_pairs) break;
         if (g.reward != nullptr) po.reward = g.reward;
         for (int t = 0; t < g.T; ++t) {
             for (int half = 0; half < 2; ++half) {
@@ -162,20 +213,25 @@ __global__ __launch_bounds__(64 * kGateWaves) __attribute__((amdgpu_waves_per_eu
                 const int e_lo = blk * kGateRows;
                 const int e_hi = (long long)(e_lo + kGateRows) < N ? e_lo + kGateRows : (int)N;
                 if (!gate_wait(g.gate_act + blk, (uint32_t)t + 1u, p)) return;
+                GATE_STAMP(t, half, 2);
+#if !defined(UAVENV_GATE_SKIP) || UAVENV_GATE_SKIP != 2      /* (timing experiments only: 2 = no env step, 1 = no table reads) */
                 const int w_lo = e_lo / EPW, n_w = (e_hi - 1) / EPW - w_lo + 1;
                 for (int w = wave; w < n_w; w += kGateWaves) {
-                    env_packed_body<BT, MODE_STEP, PLC, true, false, false, 5>(blob, g.actions + (long long)t * N, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p,
+                    env_packed_body<BT, MODE_STEP, PLC, true, false, false, kGateHO>(blob, g.actions + (long long)t * N, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p,
                                                                                s_bs, wave, (long long)(w_lo + w), 0, 1, e_lo, e_hi, &po);
                     __builtin_amdgcn_wave_barrier();
                 }
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's output stores are in the L2
                 __syncthreads();
+                GATE_STAMP(t, half, 3);
                 const bool gather = t + 1 < g.T;
                 for (int m = e_lo + wave; m < e_hi; m += kGateWaves) encode_env<KT, 8, TWO>(g, p.out, m, U, BT, N, t + 1, gather);
                 if (gather) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the encoded rows have left
                     __syncthreads();
                     if (threadIdx.x == 0) __hip_atomic_store(g.gate_obs + blk, (uint32_t)t + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    GATE_STAMP(t, half, 4);
                 }
             }
             if (g.reward != nullptr) po.reward += N;

@@ -157,8 +157,9 @@ int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, 
  * uavagent_actor_head_f32 does (bit-identical h2, logits, actions), stores the actions through and sets gate_actions[b] = t + 1.  All
  * per-step arrays are [n_steps][n_rows][...] contiguous: h1, h2_out [T][n_rows][200], uniforms and actions_out [T][n_rows], logits_out
  * [T][n_rows][ld_logits].  n_rows a multiple of 4.  The caller zeroes gate_actions and presets gate_obs (1 where h1[0] is ready) before the
- * launch and launches the two kernels on DIFFERENT streams (or parallel graph branches).  min(blocks / 2, CUs) workgroups of 8 wavefronts,
- * <= 96 VGPRs, 135 KB of LDS: one per CU, beside one workgroup of the env kernel.  Every wait is bounded (spin_us of the 100 MHz clock; 0 = 2 s):
+ * launch, zeroes `claim` (one word: pairs of blocks are handed out in arrival order, like the env kernel's) and launches the two kernels on
+ * DIFFERENT streams (or parallel graph branches).  min(blocks / 2, CUs) workgroups of 8 wavefronts, <= 128 VGPRs, 135 KB of LDS: one per CU,
+ * beside one workgroup of the env kernel.  Every wait is bounded (spin_us of the 100 MHz clock; 0 = 2 s):
  * a partner that never arrives leaves 0x47415445 "GATE" in the library's error word (uavagent_device_error; uavagent_device_error_clear)
  * and the kernel exits.  uavagent_gate_prepare() allocates that host-mapped word once per process -- call it outside any stream capture. */
 int uavagent_gate_prepare(void);
@@ -167,7 +168,7 @@ int uavagent_device_error_clear(void);
 int uavagent_actor_head_gated_f32(const float *h1, const float *w2t, const float *b2, const float *w3t_padded, const float *b3_padded,
                                   const float *uniforms, int64_t n_rows, int32_t n_steps, int32_t n_hidden, int32_t n_actions, float *h2_out,
                                   float *logits_out, int64_t ld_logits, int64_t *actions_out, uint32_t *gate_obs, uint32_t *gate_actions,
-                                  uint32_t spin_us, void *stream);
+                                  uint32_t *claim, uint32_t spin_us, void *stream);
 
 /* Weight gradient:  c[i, j] = sum_m a[m, i] * b[m, j]  and, when dbias_out != NULL, dbias_out[j] = sum_m b[m, j]  (the bias gradient of
  * the same layer: a column of ones rides along in the kernel).  a f32 [m_rows, n_i] CONTIGUOUS (n_i % 4 == 0, <= 200, 16-byte aligned),

@@ -240,9 +240,10 @@ int uavenv_debug_schedule(int64_t n_wavefronts, int64_t n_slots, int n_steps, in
  * (s_waitcnt vmcnt(0)), then store the counter; readers poll with agent-scope loads.  Every wait is BOUNDED (UAVENV_HANDOFF_SPIN_US, default
  * 2 s): a partner that never arrives -- not launched, not co-resident, crashed -- leaves error word 0x47415445 "GATE", the kernel exits and
  * the handle answers UAVENV_E_DEVICE until uavenv_set_state (uavenv_device_error).  The caller must launch both kernels on DIFFERENT streams
- * (or parallel branches of one graph) so that they can run at the same time; this one occupies min(blocks / 2, CUs) workgroups of 12
- * wavefronts with 88..96 VGPRs each on purpose: two of them never fit one CU, and one of them fits beside one partner workgroup (8 wavefronts
- * x <= 96 VGPRs, any LDS) in whatever order the dispatcher meets them.
+ * (or parallel branches of one graph) so that they can run at the same time; this one occupies min(blocks / 2, CUs) workgroups of 8
+ * wavefronts x <= 128 VGPRs, the partner should too: one workgroup of each then fills a CU exactly.  Correctness does not depend on that
+ * placement: both kernels CLAIM their pairs of blocks from a counter in arrival order (claim_dev here, the partner's own word there), so the
+ * lowest unfinished pairs are always held by resident workgroups on both sides.
  * The encoder is the first dense layer of main.py:147 / :153 applied to the raveled one-hot state of main.py:190 without forming it:
  * per env the B + U observation nodes (UAV k in plane 0 at its cell, UE in plane 1 + serving UAV) select rows (plane * G + x) * G + y of one
  * or two float32 tables [n_rows][hidden] (hidden a multiple of 4, <= 256; rows summed in node order, + bias, optionally relu6; a node off the
@@ -257,6 +258,7 @@ typedef struct UavEnvGatedRollout {
     const int64_t *actions_dev;          /* [T][N], written by the policy kernel while this launch runs */
     uint32_t *gate_actions_dev;          /* [ceil(N / 16)] */
     uint32_t *gate_obs_dev;              /* [ceil(N / 16)] */
+    uint32_t *claim_dev;                 /* one word, zero before the launch (pairs of blocks are handed out in arrival order) */
     float *reward_dev;                   /* [T][N] or NULL */
     const float *enc_table_a_dev, *enc_bias_a_dev;   /* [n_rows][hidden], [hidden] (bias may be NULL) */
     float *enc_out_a_dev;                /* [T][N][hidden] */

@@ -573,20 +573,26 @@ def test_fused_update_matches_the_autograd_update():
 
 @pytest.mark.parametrize("first,second", [(dict(collect_launch="graph", pipeline_halves=False), dict(collect_launch="eager", pipeline_halves=False)),
                                           (dict(collect_launch="graph", pipeline_halves="force"), dict(collect_launch="eager", pipeline_halves=False)),
-                                          (dict(collect_launch="eager", pipeline_halves="force"), dict(collect_launch="graph", pipeline_halves="force"))],
-                         ids=["graph_vs_eager", "pipelined_graph_vs_plain_eager", "pipelined_eager_vs_pipelined_graph"])
+                                          (dict(collect_launch="eager", pipeline_halves="force"), dict(collect_launch="graph", pipeline_halves="force")),
+                                          (dict(collect_launch="graph", pipeline_halves=False, persistent_rollout=True), dict(collect_launch="eager", pipeline_halves=False)),
+                                          (dict(collect_launch="eager", pipeline_halves=False, persistent_rollout=True), dict(collect_launch="graph", pipeline_halves="force"))],
+                         ids=["graph_vs_eager", "pipelined_graph_vs_plain_eager", "pipelined_eager_vs_pipelined_graph", "persistent_graph_vs_plain_eager",
+                              "persistent_eager_vs_pipelined_graph"])
 def test_graph_captured_rollout_equals_the_eager_rollout(first, second):
     """The rollout as a replayed hipGraph against the eager loop; and with the batch cut in two halves that ping-pong on two streams
     (A2CRunner(pipeline_halves=...): gather + env step of one half beside the actor head of the other) against the unsplit loop:
     one uniform per env and step, the same kernels on the same rows -- indices, actions, rewards, env state and, after the update,
     parameters bit for bit."""
     torch = _torch()
+    first.setdefault("persistent_rollout", False); second.setdefault("persistent_rollout", False)
     r1, r2 = _twin_runners(torch, 512, 6, max_step=15, first=dict(first), second=dict(second))
     assert (r1._halves is not None) == (first["pipeline_halves"] == "force") and (r2._halves is not None) == (second["pipeline_halves"] == "force")
+    assert r1._persistent == (first["persistent_rollout"] is True) and not r2._persistent       # (the two persistent launches instead of 3 T: see A2CRunner)
     if r1._halves is not None:
         assert r1._halves == ((0, 256), (256, 512))                # cut on a multiple of the head's 16-row tiles (inside an env wavefront: 256 = 85 x 3 + 1)
     for it in range(4):                                            # crosses done + masked reset (MAXSTEP 15 inside rollout 3)
         b1, b2 = r1.collect(), r2.collect()
+        assert r1._persistent == (first["persistent_rollout"] is True)         # (it did not fall back)
         for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):
             assert torch.equal(x, y), "%s differs in rollout %d" % (name, it)
         assert np.array_equal(r1.env.get_state(), r2.env.get_state())

@@ -38,7 +38,7 @@ def _buffers(torch, env, T, hid):
     nb = (N + env.GATE_ROWS - 1) // env.GATE_ROWS
     return dict(out_a=torch.full((T, N, hid), float("nan"), device=dev), out_c=torch.full((T, N, hid), float("nan"), device=dev),
                 idx=torch.full((T + 1, N, K), -7, dtype=torch.int64, device=dev), rew=torch.full((T, N), float("nan"), device=dev),
-                gate_act=torch.full((nb,), T, dtype=torch.int32, device=dev), gate_obs=torch.zeros(nb, dtype=torch.int32, device=dev))
+                gate_act=torch.full((nb,), T, dtype=torch.int32, device=dev), gate_obs=torch.zeros(nb, dtype=torch.int32, device=dev), claim=torch.zeros(2, dtype=torch.int32, device=dev))
 
 
 # (n_envs, n_ue, T, hidden, two tables): whole pairs of blocks; a ragged last block and a lone last block; 40 UEs (one env per wavefront,
@@ -59,7 +59,7 @@ def test_gated_rollout_with_open_gates_equals_steps_plus_first_layer(shape):
     g = torch.Generator().manual_seed(11)
     act = torch.randint(0, env.action_space_dim, (T, n), generator=g, dtype=torch.int64).to(env.device)
     b = _buffers(torch, env, T, hid)
-    env.rollout_gated(act, b["gate_act"], b["gate_obs"], wa, ba, b["out_a"], wc if two else None, bc if two else None, b["out_c"] if two else None,
+    env.rollout_gated(act, b["gate_act"], b["gate_obs"], b["claim"][0:1], wa, ba, b["out_a"], wc if two else None, bc if two else None, b["out_c"] if two else None,
                       idx_out=b["idx"], reward_out=b["rew"])
     torch.cuda.synchronize()
     assert env.device_error() == 0
@@ -101,7 +101,7 @@ def test_a_gate_that_never_opens_is_an_error_code_not_a_hang(monkeypatch):
     act = torch.zeros((T, 64), dtype=torch.int64, device=env.device)
     b = _buffers(torch, env, T, hid)
     b["gate_act"].fill_(1)                                           # step 0 may run; the actions of step 1 never come
-    env.rollout_gated(act, b["gate_act"], b["gate_obs"], wa, ba, b["out_a"], wc, bc, b["out_c"], idx_out=b["idx"], reward_out=b["rew"])
+    env.rollout_gated(act, b["gate_act"], b["gate_obs"], b["claim"][0:1], wa, ba, b["out_a"], wc, bc, b["out_c"], idx_out=b["idx"], reward_out=b["rew"])
     torch.cuda.synchronize()
     assert env.device_error() == 0x47415445
     with pytest.raises(UavEnvError):
@@ -123,10 +123,10 @@ def test_gated_rollout_refuses_what_it_was_not_built_for():
     b = _buffers(torch, env, T, hid)
     act = torch.zeros((T, 32), dtype=torch.int64, device=env.device)
     with pytest.raises(UavEnvError):
-        env.rollout_gated(act, b["gate_act"], b["gate_obs"], wa, None, b["out_a"])
+        env.rollout_gated(act, b["gate_act"], b["gate_obs"], b["claim"][0:1], wa, None, b["out_a"])
     env4 = _env(32, 20)
     with pytest.raises(ValueError):
-        env4.rollout_gated(act, b["gate_act"][:1], b["gate_obs"], wa, None, b["out_a"])
+        env4.rollout_gated(act, b["gate_act"][:1], b["gate_obs"], b["claim"][0:1], wa, None, b["out_a"])
 
 
 def _head_weights(torch, seed):
@@ -154,9 +154,10 @@ def test_gated_head_with_open_gates_equals_the_head_of_every_step(shape):
     h2, lg = torch.full((T, n, 200), float("nan"), device="cuda"), torch.full((T, n, 640), float("nan"), device="cuda")
     act = torch.full((T, n), -1, dtype=torch.int64, device="cuda")
     gate_obs, gate_act = torch.full((nb,), T, dtype=torch.int32, device="cuda"), torch.zeros(nb, dtype=torch.int32, device="cuda")
+    claim = torch.zeros(1, dtype=torch.int32, device="cuda")
     A.gate_prepare()
     A.device_error_clear()
-    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act)
+    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act, claim)
     torch.cuda.synchronize()
     assert A.device_error() == 0
     for t in range(T):
@@ -178,14 +179,15 @@ def test_gated_head_gives_up_on_a_gate_that_never_opens():
     h2, lg = torch.empty((T, n, 200), device="cuda"), torch.empty((T, n, 640), device="cuda")
     act = torch.empty((T, n), dtype=torch.int64, device="cuda")
     gate_obs, gate_act = torch.ones(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda")
+    claim = torch.zeros(1, dtype=torch.int32, device="cuda")
     A.gate_prepare()
     A.device_error_clear()
-    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act, spin_us=20000)
+    A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act, claim, spin_us=20000)
     torch.cuda.synchronize()
     assert A.device_error() == 0x47415445
     assert bool((gate_act == 1).all())                               # step 0 ran
     with pytest.raises(A.UavAgentError):
-        A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act)
+        A.actor_head_gated(h1, w2t, b2, w3t, b3p, u, NA, h2, lg, act, gate_obs, gate_act, claim)
     A.device_error_clear()
     assert A.device_error() == 0
 
@@ -217,9 +219,9 @@ def test_the_two_persistent_kernels_together_equal_the_step_by_step_rollout(shap
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
-    A.actor_head_gated(b["out_a"], w2t, b2, w3t, b3p, u, NA, h2, lg, act, b["gate_obs"], b["gate_act"])
+    A.actor_head_gated(b["out_a"], w2t, b2, w3t, b3p, u, NA, h2, lg, act, b["gate_obs"], b["gate_act"], b["claim"][1:2])
     with torch.cuda.stream(side):
-        env.rollout_gated(act, b["gate_act"], b["gate_obs"], wa, ba, b["out_a"], wc, bc, b["out_c"], idx_out=b["idx"], reward_out=b["rew"])
+        env.rollout_gated(act, b["gate_act"], b["gate_obs"], b["claim"][0:1], wa, ba, b["out_a"], wc, bc, b["out_c"], idx_out=b["idx"], reward_out=b["rew"])
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize()
     assert A.device_error() == 0 and env.device_error() == 0

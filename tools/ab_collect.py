@@ -6,16 +6,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from drl_uav_cellularnet_amd import BatchedMobiEnv
 from drl_uav_cellularnet_amd.agent import A2CRunner
-variants = {"default (pipelined halves, heads alternate)": {"pipeline_halves": True}, "unsplit (round 3)": {"pipeline_halves": False}, "separate_obs_indices": {"fused_obs": False},
+variants = {"persistent pair of gated kernels": {"persistent_rollout": True}, "default (pipelined halves, heads alternate)": {"pipeline_halves": True, "persistent_rollout": False}, "unsplit (round 3)": {"pipeline_halves": False, "persistent_rollout": False}, "separate_obs_indices": {"fused_obs": False},
             "three_launches": {"fused_head": False}}
 if len(sys.argv) > 1:
     variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
-variants["pipelined halves, EAGER launches (no graph)"] = {"pipeline_halves": True, "collect_launch": "eager"}
-variants["unsplit, EAGER launches (no graph)"] = {"pipeline_halves": False, "collect_launch": "eager"}
+variants["pipelined halves, EAGER launches (no graph)"] = {"pipeline_halves": True, "collect_launch": "eager", "persistent_rollout": False}
+variants["persistent pair, EAGER launches (no graph)"] = {"persistent_rollout": True, "collect_launch": "eager"}
+variants["unsplit, EAGER launches (no graph)"] = {"pipeline_halves": False, "collect_launch": "eager", "persistent_rollout": False}
 for parts in (2, 3, 4):
     for mode in ("alternate", "free", "stagger"):
         if (parts, mode) != (2, "alternate"):
-            variants["pipelined %d parts, %s" % (parts, mode)] = {"_mode": mode, "_parts": parts, "pipeline_halves": True}
+            variants["pipelined %d parts, %s" % (parts, mode)] = {"_mode": mode, "_parts": parts, "pipeline_halves": True, "persistent_rollout": False}
 if len(sys.argv) > 1:
     variants = {k: v for k, v in variants.items() if any(a in k for a in sys.argv[1:])}
 runners = {}

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Timing of the two persistent rollout kernels at BASELINE config 3's shape (8192 envs x 50 steps): each ALONE with its gates open (it then
+runs its T steps without waiting), and the pair with closed gates.  ms per launch, best / median of `reps`."""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from drl_uav_cellularnet_amd import BatchedMobiEnv
+from drl_uav_cellularnet_amd import _agent_capi as A
+
+N, T, reps = int(os.environ.get("N", 8192)), int(os.environ.get("T", 50)), 7
+env = BatchedMobiEnv(N, nBS=4, nUE=20, grid_n=100, groups=[5, 5, 5, 5])
+dev = env.device
+g = torch.Generator(device="cuda").manual_seed(1)
+rows, hid, K = 5 * 100 * 100, 200, 24
+rnd = lambda *s: torch.rand(s, device=dev, generator=g) * 2.0 - 1.0
+wa, ba, wc, bc = rnd(rows, hid) * 0.1, rnd(hid), rnd(rows, hid) * 0.1, rnd(hid)
+w2t, b2 = (rnd(hid, hid) * 0.2).contiguous(), rnd(hid)
+w3t, b3p = torch.zeros((640, hid), device=dev), torch.zeros(640, device=dev)
+w3t[:625], b3p[:625] = rnd(625, hid) * 0.3, rnd(625)
+u = torch.rand((T, N), device=dev, generator=g)
+h1a, h1c = torch.rand((T, N, hid), device=dev, generator=g) * 6, torch.empty((T, N, hid), device=dev)
+h2, lg = torch.empty((T, N, hid), device=dev), torch.empty((T, N, 640), device=dev)
+act = torch.randint(0, 625, (T, N), device=dev, generator=g)
+idx = torch.empty((T + 1, N, K), dtype=torch.int64, device=dev)
+rew = torch.empty((T, N), device=dev)
+nb = (N + 15) // 16
+g_obs, g_act = torch.zeros(nb, dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev)
+claim = torch.zeros(2, dtype=torch.int32, device=dev)
+A.gate_prepare()
+side = torch.cuda.Stream(device=dev)
+
+
+def timed(fn):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return {"best_ms": round(ts[0], 3), "median_ms": round(ts[len(ts) // 2], 3)}
+
+
+def env_alone():
+    g_act.fill_(T); g_obs.zero_(); claim.zero_()
+    env.rollout_gated(act, g_act, g_obs, claim[0:1], wa, ba, h1a, wc, bc, h1c, idx_out=idx, reward_out=rew)
+
+
+def head_alone():
+    g_obs.fill_(T); g_act.zero_(); claim.zero_()
+    A.actor_head_gated(h1a, w2t, b2, w3t, b3p, u, 625, h2, lg, act, g_obs, g_act, claim[1:2])
+
+
+def pair():
+    g_obs.fill_(1); g_act.zero_(); claim.zero_()
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    A.actor_head_gated(h1a, w2t, b2, w3t, b3p, u, 625, h2, lg, act, g_obs, g_act, claim[1:2])
+    with torch.cuda.stream(side):
+        env.rollout_gated(act, g_act, g_obs, claim[0:1], wa, ba, h1a, wc, bc, h1c, idx_out=idx, reward_out=rew)
+    main.wait_stream(side)
+
+
+res = {"n_envs": N, "steps": T}
+legs = [("env_kernel_alone_open_gates", env_alone), ("head_kernel_alone_open_gates", head_alone)] + ([] if os.environ.get("SKIP_PAIR") else [("pair", pair)])
+for name, fn in legs:
+    fn(); torch.cuda.synchronize()
+    res[name] = timed(fn)
+    assert A.device_error() == 0 and env.device_error() == 0, name
+print(json.dumps(res))
