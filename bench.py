@@ -578,6 +578,7 @@ def measure_a2c(args, dist, dev, reduce_dev, rank, world, envs, rollouts, rollou
             "collect_launch": getattr(runner, "collect_launch", "eager"), "gemm_tuning": bool(getattr(runner, "gemm_tuning", False)),
             "a_loss": st.get("a_loss"), "c_loss": st.get("c_loss"), "mean_reward": st.get("mean_reward"),
             "roofline": roof, "pipeline_halves": getattr(runner, "_halves", None) is not None,
+            "persistent_rollout": bool(getattr(runner, "_persistent", False)),
             "config": "%d envs/GPU x 4 UAV x 20 UE, MLP 50000->200->200->{625,1}, fp32, %d-step rollouts, 1 update per rollout"
                       % (envs, rollout_len)}
 
@@ -603,6 +604,21 @@ def a2c_roofline(runner, envs, T):
     n_parts = len(parts)
     Nr = (parts[0][1] - parts[0][0])                           # rows per rollout-kernel launch (the parts are equal at 8192 envs)
     was = runner.collect_launch
+    # (the timed region may have collected with the two persistent rollout kernels -- A2CRunner(persistent_rollout) --, whose launches last a
+    #  whole rollout each and wait for each other; the per-kernel figures below are of the per-step kernels, which compute the same rows)
+    was_persistent = bool(getattr(runner, "_persistent", False))
+    pair_ms = None
+    if was_persistent:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        runner.u_buf.uniform_(generator=runner.gen)
+        runner._refresh_transposed()
+        torch.cuda.synchronize()
+        e0.record()
+        runner._rollout_steps()                      # first layer of the start state, gates, the two persistent launches on two streams, join
+        e1.record()
+        torch.cuda.synchronize()
+        pair_ms = e0.elapsed_time(e1)
+        runner._persistent = False
     runner.collect_launch = "eager"
     torch.cuda.synchronize()
     A.profile_begin()
@@ -612,6 +628,7 @@ def a2c_roofline(runner, envs, T):
     finally:
         times = A.profile_end()
         runner.collect_launch = was
+        runner._persistent = was_persistent
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     act = runner.act_buf[0]
     e0.record()
@@ -666,7 +683,18 @@ def a2c_roofline(runner, envs, T):
                        "frac": b_step * N / (env_us * 1e-6) / 1e12 / (HBM_PEAK_GBPS / 1e3), "roof_source": "HBM peak (nominal, as the headline's roofline.frac)",
                        "launches_timed": T}
     covered = sum(v["ms_per_rollout"] for v in out.values())
-    return {"kernels": out, "ms_per_rollout_covered": covered, "rollout_parts_on_streams": n_parts,
+    pair = None
+    if pair_ms is not None:
+        flops = 2.0 * N * T * (H * H + H * NA)
+        gbytes = float(N) * (T - 1) * K * 2 * H * 4
+        pair = {"what": "the rollout the timed region ran: uavagent_actor_head_gated_f32 beside uavenv_rollout_gated, two persistent launches that hand "
+                        "16-env blocks to each other through step counters in device memory (per-step kernels above: the same rows, one launch each)",
+                "ms_per_rollout": pair_ms, "policy_flop": flops, "policy_TFLOPs": flops / (pair_ms * 1e-3) / 1e12,
+                "policy_frac_of_mfma_peak": flops / (pair_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "encoder_bytes": gbytes, "encoder_TBps": gbytes / (pair_ms * 1e-3) / 1e12,
+                "encoder_frac_of_gather_roof": gbytes / (pair_ms * 1e-3) / 1e12 / GATHER_CACHE_TBPS,
+                "note": "both kernels run for the whole rollout, so each rate is its work over the PAIR's time"}
+    return {"kernels": out, "persistent_rollout_pair": pair, "ms_per_rollout_covered": covered, "rollout_parts_on_streams": n_parts,
             "ms_per_rollout_covered_note": "sum of avg_us x calls; with the rollout pipelined over two streams the halves' kernels overlap, so the "
                                            "sum exceeds the wall time of a rollout + update",
             "method": "HIP events around every launch of one extra EAGER rollout + update of this run (after the timed region); back-to-back launches "

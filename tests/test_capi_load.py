@@ -47,7 +47,7 @@ def test_agent_library_exports_its_header():
     names = sorted(set(re.findall(r"\b(uavagent_[a-z0-9_]+)\s*\(", text)))
     lib = _agent_capi.load()
     assert set(names) == set(_agent_capi.EXPORTS) and all(hasattr(lib, n) for n in names)
-    assert lib.uavagent_abi_version() == _agent_capi.ABI_VERSION == 4
+    assert lib.uavagent_abi_version() == _agent_capi.ABI_VERSION == 5
     assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 1, 24, 200, 100, None) == -1
     assert b"null" in lib.uavagent_last_error()
     assert lib.uavagent_sparse_rows_sum_f32(None, None, None, None, None, None, None, 0, 24, 200, 100, None) == 0   # empty batch
@@ -57,6 +57,12 @@ def test_agent_library_exports_its_header():
     assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 1, 24, 200, 2 ** 40, None) == -1
     assert b"4 GiB" in lib.uavagent_last_error()
     assert lib.uavagent_sparse_rows_sum_f32(one, None, one, None, None, None, one, 0, 24, 200, 100, None) == 0   # m_rows = 0: no launch
+    # ABI 5: the gated head of a whole rollout refuses before any launch without its error word, with null gates, with unaligned step blocks
+    gh = lib.uavagent_actor_head_gated_f32
+    assert gh(one, one, one, one, one, one, 64, 5, 200, 625, one, one, 640, one, None, one, one, 0, None) == -1 and b"null" in lib.uavagent_last_error()
+    assert gh(one, one, one, one, one, one, 66, 5, 200, 625, one, one, 640, one, one, one, one, 0, None) == -1 and b"multiple of 4" in lib.uavagent_last_error()
+    code = ctypes.c_uint32(7)
+    assert lib.uavagent_device_error(ctypes.byref(code)) == 0 and code.value == 0
     # ABI 4: the same layer fed from the compact observation (argument order: tables, ue_xy, bs_xy, serving, n_envs, n_ue, n_bs, grid, h, n_rows)
     flo = lib.uavagent_first_layer_from_obs_f32
     assert flo(one, None, one, None, None, None, one, one, one, 8, 61, 4, 100, 200, 50000, 1, None, None) == -1
