@@ -405,6 +405,10 @@ class A2CRunner:
         # timeout surfaces as RuntimeError from collect().  "auto" = from 4096 envs on; True = whenever the shapes allow (tests); the first
         # collect() proves on a CLONE of the env state that the two kernels do run side by side, and falls back to pipeline_halves if not.
         self._persistent = False
+        self._persist_stream = None
+        self._persistent_proven = False
+        self._persist_same_stream = _os.environ.get("UAVAGENT_PERSIST_SAME_STREAM", "0") == "1"
+        self._gate_spin_us = int(_os.environ.get("UAVAGENT_GATE_SPIN_US", "0"))     # 0 = the library's 2 s
         if (persistent_rollout and self.dev.type == "cuda" and self.fused_head and self.fused_obs and env.nBS == 4 and env.nUE <= 64
                 and env.n_envs % 4 == 0 and (persistent_rollout is True or env.n_envs >= 4096)):
             self._persistent = True
@@ -530,20 +534,51 @@ class A2CRunner:
         self._gate_act.zero_()
         self._gate_claim.zero_()
         main = torch.cuda.current_stream(self.dev)
-        if not self._pipe_streams:
-            self._pipe_streams.append(torch.cuda.Stream(device=self.dev))
-        side = self._pipe_streams[0]
+        if self._persist_stream is None:
+            # a stream of its own, HIGH priority: the runtime keeps separate hardware queues per priority level, so this stream cannot land on
+            # the queue of the (normal-priority) stream the policy kernel is launched on -- two kernels that wait for each other must never sit
+            # behind one another in ONE queue (that ends in the bounded waits' error code, and in the fallback of _prove_persistent)
+            self._persist_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        side = self._persist_stream
+        if self._persist_same_stream:                # test hook (UAVAGENT_PERSIST_SAME_STREAM=1): both kernels in ONE queue, i.e. never side by side
+            side = main
         fork = torch.cuda.Event()
         fork.record(main)
         side.wait_event(fork)
         A.actor_head_gated(fw["h1a"], wt["a_w2t"], net.a_b2, wt["a_w3t"], wt["a_b3p"], self.u_buf, net.n_action, fw["h2a"], self._logits_pad, self.act_buf,
-                           self._gate_obs, self._gate_act, self._gate_claim[1:2])
+                           self._gate_obs, self._gate_act, self._gate_claim[1:2], spin_us=self._gate_spin_us)
         with torch.cuda.stream(side):
             env.rollout_gated(self.act_buf, self._gate_act, self._gate_obs, self._gate_claim[0:1], net.a_w1, net.a_b1, fw["h1a"], net.c_w1, net.c_b1, fw["h1c"],
                               idx_out=self.idx_buf, reward_out=self.rew_buf)
         join = torch.cuda.Event()
         join.record(side)
         main.wait_event(join)
+
+    def _prove_persistent(self):
+        """Eager launches: one trial rollout on a CLONE of the env state shows whether the two persistent kernels run side by side on the
+        streams this runner uses (the stream -> hardware-queue mapping is fixed when a stream is created); if not, the per-step launches take
+        over for good.  (The captured form has the same trial in _capture.)"""
+        env = self.env
+        state = torch.empty(env._lay.total_bytes, dtype=torch.uint8, device=self.dev)
+        env.copy_state_to(state)
+        keep = {k: v.clone() for k, v in env.out.items()}
+        keep_idx = self.idx_buf[self.T].clone()
+        self._rollout_steps()
+        torch.cuda.synchronize(self.dev)
+        failed = self._persistent_failed()
+        if failed:
+            import warnings
+            from . import _agent_capi as A
+
+            warnings.warn("A2CRunner: the persistent rollout kernels did not run side by side (eager trial: a gate wait timed out); using the "
+                          "per-step launches instead")
+            self._persistent = False
+            A.device_error_clear()
+        env.copy_state_from(state)                     # (also clears the env handle's device-error word)
+        for k, v in keep.items():
+            env.out[k].copy_(v)
+        self.idx_buf[self.T].copy_(keep_idx)
+        self._persistent_proven = True
 
     def _persistent_failed(self):
         """True when a gated launch gave up on the device (both libraries keep a sticky word in host-mapped memory)."""
@@ -621,6 +656,8 @@ class A2CRunner:
         if self.collect_launch == "graph" and self._graph is not None:
             self._graph.replay()
         else:
+            if self._persistent and not self._persistent_proven:
+                self._prove_persistent()
             self._rollout_steps()
         self._fwd_valid = self._fwd is not None
         self.ep_r += self.rew_buf.sum(dim=0)
@@ -703,6 +740,7 @@ class A2CRunner:
                     give_up_persistent("trial replay of the captured graph")
                     continue
                 restore()
+                self._persistent_proven = True
             self._graph = g
             return
 

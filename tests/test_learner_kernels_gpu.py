@@ -603,6 +603,33 @@ def test_graph_captured_rollout_equals_the_eager_rollout(first, second):
     assert r1.running_r is not None and r1.running_r == r2.running_r
 
 
+@pytest.mark.parametrize("launch", ["eager", "graph"])
+def test_persistent_rollout_falls_back_when_its_kernels_cannot_run_side_by_side(launch, monkeypatch):
+    """The two persistent rollout kernels wait for each other, so they must run at the same time.  With both in ONE stream (test hook) the
+    first waits in vain: every wait is bounded, the trial on a clone of the env state sees the error words, and the runner goes on with the
+    per-step launches -- same results as a runner that never tried, nothing hangs, the env handle is usable."""
+    torch = _torch()
+    import warnings
+
+    monkeypatch.setenv("UAVAGENT_PERSIST_SAME_STREAM", "1")
+    monkeypatch.setenv("UAVAGENT_GATE_SPIN_US", "30000")           # 30 ms
+    monkeypatch.setenv("UAVENV_HANDOFF_SPIN_US", "30000")          # (read in uavenv_create)
+    r1, r2 = _twin_runners(torch, 256, 5, first=dict(collect_launch=launch, persistent_rollout=True, pipeline_halves=False),
+                           second=dict(collect_launch="eager", persistent_rollout=False, pipeline_halves=False))
+    assert r1._persistent
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        b1 = r1.collect()
+    assert not r1._persistent and any("side by side" in str(x.message) for x in w)
+    b2 = r2.collect()
+    for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):
+        assert torch.equal(x, y), name
+    assert np.array_equal(r1.env.get_state(), r2.env.get_state()) and r1.env.device_error() == 0
+    r1.update(*b1); r2.update(*b2)
+    b1, b2 = r1.collect(), r2.collect()
+    assert torch.equal(b1[1], b2[1]) and torch.equal(r1.flat.w, r2.flat.w)
+
+
 def test_fused_update_is_bit_identical_with_and_without_forward_reuse():
     """update_fused computes the critic's layer 2 with ONE arithmetic (W2^T through the k-contiguous kernels) whether it reuses the
     rollout's forward pass or recomputes it (first update after load_state_dict, external buffers): same parameters bit for bit

@@ -217,7 +217,7 @@ def test_the_two_persistent_kernels_together_equal_the_step_by_step_rollout(shap
     A.gate_prepare()
     A.device_error_clear()
     torch.cuda.synchronize()
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=-1)    # its own hardware queue (priority levels have separate queues): the two kernels wait for each other
     side.wait_stream(torch.cuda.current_stream(dev))
     A.actor_head_gated(b["out_a"], w2t, b2, w3t, b3p, u, NA, h2, lg, act, b["gate_obs"], b["gate_act"], b["claim"][1:2])
     with torch.cuda.stream(side):

@@ -28,7 +28,7 @@ nb = (N + 15) // 16
 g_obs, g_act = torch.zeros(nb, dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev)
 claim = torch.zeros(2, dtype=torch.int32, device=dev)
 A.gate_prepare()
-side = torch.cuda.Stream(device=dev)
+side = torch.cuda.Stream(device=dev, priority=-1)
 
 
 def timed(fn):

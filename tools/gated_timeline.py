@@ -32,7 +32,7 @@ stamps = torch.zeros((T, 2, 8), dtype=torch.int64, device=dev)
 A.gate_prepare()
 assert _capi.load().uavenv_debug_set_gate_stamps(C.c_void_p(stamps.data_ptr())) == 0
 assert A.load().uavagent_debug_set_gate_stamps(C.c_void_p(stamps.data_ptr())) == 0
-side = torch.cuda.Stream(device=dev)
+side = torch.cuda.Stream(device=dev, priority=-1)
 
 
 def pair():
