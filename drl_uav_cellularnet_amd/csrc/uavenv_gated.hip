@@ -49,8 +49,9 @@ extern "C" int uavenv_rollout_gated(uavenv_t *h, const UavEnvGatedRollout *r, co
         if (two) hipLaunchKernelGGL((env_kernel_gated<4, PLC_, KT_, true>), dim3(grid), blk, 0, s, GATED_ARGS);          \
         else hipLaunchKernelGGL((env_kernel_gated<4, PLC_, KT_, false>), dim3(grid), blk, 0, s, GATED_ARGS);             \
     } while (0)
-    if (h->plc) { if (K == 24) GATED_LAUNCH(true, 24); else GATED_LAUNCH(true, 0); }
-    else { if (K == 24) GATED_LAUNCH(false, 24); else GATED_LAUNCH(false, 0); }
+    // (the node count as a template parameter for the reference's two shapes, 4 UAVs + 20 / 40 UEs: the row loop unrolls around v_readlane)
+    if (h->plc) { if (K == 24) GATED_LAUNCH(true, 24); else if (K == 44) GATED_LAUNCH(true, 44); else GATED_LAUNCH(true, 0); }
+    else { if (K == 24) GATED_LAUNCH(false, 24); else if (K == 44) GATED_LAUNCH(false, 44); else GATED_LAUNCH(false, 0); }
 #undef GATED_LAUNCH
 #undef GATED_ARGS
     HIP_TRY(hipGetLastError());

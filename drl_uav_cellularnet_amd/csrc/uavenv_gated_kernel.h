@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_ga
                 __syncthreads();
                 GATE_STAMP(t, half, 3);
                 const bool gather = t + 1 < g.T;
-                for (int m = e_lo + wave; m < e_hi; m += kGateWaves) encode_env<KT, 8, TWO>(g, p.out, m, U, BT, N, t + 1, gather);
+                for (int m = e_lo + wave; m < e_hi; m += kGateWaves) encode_env<KT, (KT == 44 ? 4 : 8), TWO>(g, p.out, m, U, BT, N, t + 1, gather);   // (UNR as in sparse_rows_sum_kernel: 24 = 3 x 8, 44 = 11 x 4)
                 if (gather) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the encoded rows have left
                     __syncthreads();

@@ -42,8 +42,8 @@ def _buffers(torch, env, T, hid):
 
 
 # (n_envs, n_ue, T, hidden, two tables): whole pairs of blocks; a ragged last block and a lone last block; 40 UEs (one env per wavefront,
-# run-time node count); one table; more pairs than a small grid would hold
-SHAPES = [(64, 20, 6, 200, True), (200, 20, 5, 200, True), (16 * 3 + 5, 20, 4, 200, True), (40, 40, 4, 200, True), (96, 20, 3, 64, False),
+# 44 nodes); one table; a node count without an instantiation of its own (36: run-time loop); more pairs than a small grid would hold
+SHAPES = [(64, 20, 6, 200, True), (200, 20, 5, 200, True), (16 * 3 + 5, 20, 4, 200, True), (40, 40, 4, 200, True), (96, 20, 3, 64, False), (48, 32, 3, 200, True),
           (8192, 20, 3, 200, True)]
 
 

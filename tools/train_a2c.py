@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--first-state", choices=("obs", "zeros"), default="zeros")
     ap.add_argument("--checkpoint-every", type=int, default=0, help="episodes between full checkpoints (<out>/checkpoint_rank<r>.pt); 0 = never")
     ap.add_argument("--resume", action="store_true", help="continue from <out>/checkpoint_rank<r>.pt (bit-identical to an uninterrupted run)")
+    ap.add_argument("--rollout-form", choices=("auto", "per-step"), default="auto", help="auto: A2CRunner's default (the two persistent rollout kernels from "
+                    "4096 workers on); per-step: the pipelined per-step launches (same results bit for bit)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave PyTorch's TunableOp off (library default; this tool turns the "
                     "shipped per-shape GEMM picks on: a resumed run is bit-identical only if it makes the same choice as the original)")
     a = ap.parse_args()
@@ -78,7 +80,8 @@ def main():
 
     base, _ = shard_for_rank(rank, world, a.workers)
     env = BatchedMobiEnv(a.workers, nBS=4, nUE=a.n_ue, grid_n=a.grid, device=dev, env_id_base=base)
-    runner = A2CRunner(env, rollout=a.rollout, first_state=a.first_state, tune_gemms=not a.no_gemm_tuning)
+    runner = A2CRunner(env, rollout=a.rollout, first_state=a.first_state, tune_gemms=not a.no_gemm_tuning,
+                       persistent_rollout="auto" if a.rollout_form == "auto" else False)
     per_episode = int(env.cfg.max_step) // a.rollout                       # a2c_single_thread.py:108
     returns, t0, first_ep = [], time.time(), 0
     ckpt = os.path.join(a.out, "checkpoint_rank%d.pt" % rank)
