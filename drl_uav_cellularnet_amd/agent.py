@@ -402,7 +402,7 @@ class A2CRunner:
         # layer) -- that hand 16-env blocks to each other through step counters in device memory (include/uavenv.h has the protocol): no kernel
         # boundary, graph node or cross-stream edge per step any more; each CU hosts one workgroup of either kernel and ping-pongs between the
         # two blocks of its pair.  Same arithmetic per env and step: bit-identical to the other forms.  Every device-side wait is bounded; a
-        # timeout surfaces as RuntimeError from collect().  "auto" = from 4096 envs on; True = whenever the shapes allow (tests); the first
+        # timeout makes collect() restore the state the rollout started from and collect it again with the per-step launches.  "auto" = from 4096 envs on; True = whenever the shapes allow (tests); the first
         # collect() proves on a CLONE of the env state that the two kernels do run side by side, and falls back to pipeline_halves if not.
         self._persistent = False
         self._persist_stream = None
@@ -442,6 +442,7 @@ class A2CRunner:
             self._gate_obs = torch.zeros(nb, dtype=torch.int32, device=self.dev)
             self._gate_act = torch.zeros(nb, dtype=torch.int32, device=self.dev)
             self._gate_claim = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            self._persist_state = torch.empty(env._lay.total_bytes, dtype=torch.uint8, device=self.dev)
             from . import _agent_capi as _A
 
             _A.gate_prepare()
@@ -528,6 +529,7 @@ class A2CRunner:
         from . import _agent_capi as A
 
         env, T, net, fw, wt = self.env, self.T, self.net, self._fwd, self._wt
+        env.copy_state_to(self._persist_state)       # one 11 MB device copy per rollout: what collect() falls back on if a kernel gives up
         self.idx_buf[0].copy_(self.idx_buf[T])
         A.sparse_rows_sum(self.idx_buf[0], net.a_w1, net.a_b1, net.c_w1, net.c_b1, relu6=True, out_a=fw["h1a"][0], out_c=fw["h1c"][0])
         self._gate_obs.fill_(1)
@@ -653,25 +655,39 @@ class A2CRunner:
                 warnings.warn("A2CRunner: hipGraph capture of the rollout failed (%s: %s); collecting eagerly" % (type(ex).__name__, ex))
                 self.collect_launch = "eager"
                 self._graph = None
+        persistent_ran = self._persistent
         if self.collect_launch == "graph" and self._graph is not None:
             self._graph.replay()
         else:
             if self._persistent and not self._persistent_proven:
                 self._prove_persistent()
+                persistent_ran = self._persistent
             self._rollout_steps()
-        self._fwd_valid = self._fwd is not None
-        self.ep_r += self.rew_buf.sum(dim=0)
         done = env.out["done"].bool()
-        persistent_ran = self._persistent
-        boot = self.net.critic_only(self.idx_buf[T]).squeeze(1)                      # :173-176
-        boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
         any_done = bool(done.any())                                                  # (host sync: the rollout's kernels have finished)
         if persistent_ran and self._persistent_failed():
+            # A persistent rollout kernel gave up waiting for its partner in the MIDDLE of a run (they had been proven to run side by side: so
+            # something else kept one of them off the chip for longer than the spin budget).  Nothing is lost: the rollout started from the
+            # state snapshot _rollout_steps_persistent took, the uniforms are still in u_buf -- restore, switch to the per-step launches for
+            # good, and collect this rollout again: same results as if the persistent kernels had finished.
+            import warnings
             from . import _agent_capi as _A2
 
-            raise RuntimeError("A2CRunner.collect: a persistent rollout kernel gave up waiting for its partner (device error words: policy 0x%08x, "
-                               "env 0x%08x); the env state is incomplete -- set_state() / load_state_dict() before going on"
-                               % (_A2.device_error(), env.device_error()))
+            warnings.warn("A2CRunner.collect: a persistent rollout kernel gave up waiting for its partner (device error words: policy 0x%08x, env "
+                          "0x%08x); the rollout is collected again with the per-step launches, which this runner uses from now on"
+                          % (_A2.device_error(), env.device_error()))
+            _A2.device_error_clear()
+            env.copy_state_from(self._persist_state)                                 # (also clears the env handle's device-error word)
+            self.idx_buf[T].copy_(self.idx_buf[0])
+            self._persistent = False
+            self._graph = None                                                       # (the next collect() captures the per-step form)
+            self._rollout_steps()
+            done = env.out["done"].bool()
+            any_done = bool(done.any())
+        self._fwd_valid = self._fwd is not None
+        self.ep_r += self.rew_buf.sum(dim=0)
+        boot = self.net.critic_only(self.idx_buf[T]).squeeze(1)                      # :173-176
+        boot = torch.where(done, torch.zeros_like(boot), boot)                       # value_estimate = 0 when done
         if any_done:                                                                 # :167-172 reset_worker
             m = float(self.ep_r[done].mean())
             self.last_episode_return = m                                             # mean return of the episodes that just ended

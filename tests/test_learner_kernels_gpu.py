@@ -630,6 +630,32 @@ def test_persistent_rollout_falls_back_when_its_kernels_cannot_run_side_by_side(
     assert torch.equal(b1[1], b2[1]) and torch.equal(r1.flat.w, r2.flat.w)
 
 
+def test_persistent_rollout_recovers_when_a_kernel_gives_up_in_the_middle_of_a_run(monkeypatch):
+    """After the trial has shown the two kernels side by side, a later rollout's wait still times out (here: the test hook moves both kernels
+    into one stream).  collect() restores the state snapshot the rollout started from, switches to the per-step launches for good and collects the
+    rollout again: the caller sees a warning and the results of an undisturbed run."""
+    torch = _torch()
+    import warnings
+
+    monkeypatch.setenv("UAVENV_HANDOFF_SPIN_US", "30000")          # (read in uavenv_create)
+    r1, r2 = _twin_runners(torch, 256, 5, max_step=12, first=dict(collect_launch="eager", persistent_rollout=True, pipeline_halves=False),
+                           second=dict(collect_launch="eager", persistent_rollout=False, pipeline_halves=False))
+    for it in range(4):
+        if it == 2:
+            r1._persist_same_stream, r1._gate_spin_us = True, 30000
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            b1 = r1.collect()
+        b2 = r2.collect()
+        assert r1._persistent == (it < 2) and (it != 2 or any("gave up" in str(x.message) for x in w))
+        for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):
+            assert torch.equal(x, y), "%s differs in rollout %d" % (name, it)
+        assert np.array_equal(r1.env.get_state(), r2.env.get_state()) and r1.env.device_error() == 0
+        r1.update(*b1); r2.update(*b2)
+        assert torch.equal(r1.flat.w, r2.flat.w)
+    assert r1.running_r == r2.running_r
+
+
 def test_fused_update_is_bit_identical_with_and_without_forward_reuse():
     """update_fused computes the critic's layer 2 with ONE arithmetic (W2^T through the k-contiguous kernels) whether it reuses the
     rollout's forward pass or recomputes it (first update after load_state_dict, external buffers): same parameters bit for bit
