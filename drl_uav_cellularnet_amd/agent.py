@@ -405,6 +405,8 @@ class A2CRunner:
         # timeout makes collect() restore the state the rollout started from and collect it again with the per-step launches.  "auto" = from 4096 envs on; True = whenever the shapes allow (tests); the first
         # collect() proves on a CLONE of the env state that the two kernels do run side by side, and falls back to pipeline_halves if not.
         self._persistent = False
+        if _os.environ.get("UAVAGENT_PERSISTENT") in ("0", "1"):          # A/B runs (tools, bench): overrides the argument
+            persistent_rollout = _os.environ["UAVAGENT_PERSISTENT"] == "1"
         self._persist_stream = None
         self._persistent_proven = False
         self._persist_same_stream = _os.environ.get("UAVAGENT_PERSIST_SAME_STREAM", "0") == "1"
@@ -600,6 +602,10 @@ class A2CRunner:
         main = torch.cuda.current_stream(self.dev)
         P = len(self._halves)
         while len(self._pipe_streams) < P - 1:
+            # (normal priority.  A high-priority stream would have a hardware queue of its own -- with a dozen streams alive in one process the
+            #  side stream can end up in the calling stream's queue, where the halves run one after the other: 8.8-10.3 instead of 4.4 ms in a
+            #  five-runner A/B process, profiles/r04fd_ab_collect_five_runners_in_one_process.json -- but the captured graph then runs the rollout in
+            #  12.9 ms: profiles/r04gu_ab_bench_a2c_pipelined_on_a_high_priority_stream.txt)
             self._pipe_streams.append(torch.cuda.Stream(device=self.dev))
         streams = [main] + self._pipe_streams[:P - 1]
         fork = torch.cuda.Event()
