@@ -412,7 +412,7 @@ class A2CRunner:
         self._persist_same_stream = _os.environ.get("UAVAGENT_PERSIST_SAME_STREAM", "0") == "1"
         self._gate_spin_us = int(_os.environ.get("UAVAGENT_GATE_SPIN_US", "0"))     # 0 = the library's 2 s
         if (persistent_rollout and self.dev.type == "cuda" and self.fused_head and self.fused_obs and env.nBS == 4 and env.nUE <= 64
-                and env.n_envs % 4 == 0 and (persistent_rollout is True or env.n_envs >= 4096)):
+                and env.n_envs % 4 == 0 and "cur_sinr_f64" not in env.out and (persistent_rollout is True or env.n_envs >= 4096)):
             self._persistent = True
         N, T, K = env.n_envs, self.T, env.nBS + env.nUE
         # rollout buffers (persistent: the captured graph holds their addresses).  idx_buf[t] = observation BEFORE step t,
@@ -567,15 +567,19 @@ class A2CRunner:
         env.copy_state_to(state)
         keep = {k: v.clone() for k, v in env.out.items()}
         keep_idx = self.idx_buf[self.T].clone()
-        self._rollout_steps()
+        refused = None
+        try:
+            self._rollout_steps()
+        except Exception as ex:                        # an entry point refused the shapes before launching anything
+            refused = ex
         torch.cuda.synchronize(self.dev)
-        failed = self._persistent_failed()
+        failed = refused is not None or self._persistent_failed()
         if failed:
             import warnings
             from . import _agent_capi as A
 
-            warnings.warn("A2CRunner: the persistent rollout kernels did not run side by side (eager trial: a gate wait timed out); using the "
-                          "per-step launches instead")
+            warnings.warn("A2CRunner: the persistent rollout kernels did not run side by side (eager trial: %s); using the per-step launches "
+                          "instead" % ("refused: %s" % refused if refused is not None else "a gate wait timed out"))
             self._persistent = False
             A.device_error_clear()
         env.copy_state_from(state)                     # (also clears the env handle's device-error word)
@@ -741,12 +745,18 @@ class A2CRunner:
         s = torch.cuda.Stream(device=self.dev)
         for attempt in range(2):
             s.wait_stream(torch.cuda.current_stream(self.dev))
+            refused = None
             with torch.cuda.stream(s):
-                self._rollout_steps()
+                try:
+                    self._rollout_steps()
+                except Exception as ex:                    # (persistent form: an entry point refused the shapes before launching anything)
+                    if not self._persistent:
+                        raise
+                    refused = ex
             torch.cuda.current_stream(self.dev).wait_stream(s)
             torch.cuda.synchronize(self.dev)
-            if self._persistent and self._persistent_failed():
-                give_up_persistent("eager warm-up pass")
+            if self._persistent and (refused is not None or self._persistent_failed()):
+                give_up_persistent("eager warm-up pass" + (", refused: %s" % refused if refused is not None else ""))
                 continue
             restore()
             # capture_error_mode="thread_local": with torch.distributed initialised, RCCL's watchdog thread polls events while this
