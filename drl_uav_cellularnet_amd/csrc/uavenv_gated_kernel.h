@@ -115,20 +115,27 @@ __device__ __forceinline__ float4 enc_load4(const char *q) {
 #endif
 }
 
-// The encoder for env m (one wavefront).  KT > 0: B + U known at compile time (the row loop unrolls by UNR around v_readlane).
-template <int KT, int UNR, bool TWO>
-__device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &obs, long long m, int U, int B, long long N, int t_slot, bool gather) {
+// The encoder, one wavefront for NS envs of the block: m, m + m_stride, ... (n_here <= NS of them exist).  KT > 0: B + U known at compile time (the
+// row loop unrolls by UNR around v_readlane).  NS = 2 (2 KT <= 64): the observation of BOTH envs is read and turned into row indices first --
+// lanes [0, K) the first env, [K, 2 K) the second -- so that a wavefront pays that round trip once per block and step, not once per env; the rows
+// are then gathered env by env.
+template <int KT, int UNR, bool TWO, int NS>
+__device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &obs, long long m, long long m_stride, int n_here, int U, int B, long long N,
+                                           int t_slot, bool gather) {
+    static_assert(NS == 1 || (KT > 0 && NS * KT <= 64), "several envs per wavefront: their nodes share its 64 lanes");
     const int lane = threadIdx.x & 63;
     const int K = KT > 0 ? KT : U + B;
-    long long mine = 0;
-    if (lane < K) {
+    const int sl = NS > 1 ? lane / K : 0, k = NS > 1 ? lane - sl * K : lane;
+    long long mine = -1ll;
+    if (lane < NS * K && sl < n_here) {
+        const long long me = m + sl * m_stride;
         int x, y, pl;
-        if (lane < B) {     // (written by other wavefronts of this workgroup a moment ago: see kGateHO)
+        if (k < B) {     // (written by other wavefronts of this workgroup a moment ago: see kGateHO)
             union { unsigned long long w; int2 c; } q;
-            q.w = GATE_OBS_LOAD(reinterpret_cast<const unsigned long long *>(obs.bs_xy) + (m * B + lane));
+            q.w = GATE_OBS_LOAD(reinterpret_cast<const unsigned long long *>(obs.bs_xy) + (me * B + k));
             x = q.c.x; y = q.c.y; pl = 0;
         } else {
-            const long long iu = m * U + (lane - B);
+            const long long iu = me * U + (k - B);
             union { uint32_t w; short2 c; } q;
             q.w = GATE_OBS_LOAD(reinterpret_cast<const uint32_t *>(obs.ue_xy) + iu);
             x = q.c.x; y = q.c.y;
@@ -136,52 +143,58 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
         }
         const bool ok = x >= 0 && x < g.G && y >= 0 && y < g.G && pl >= 0 && pl <= B;
         mine = ok ? ((long long)pl * g.G + x) * g.G + y : -1ll;
-        if (g.idx_out != nullptr) g.idx_out[((long long)t_slot * N + m) * K + lane] = mine;
+        if (g.idx_out != nullptr) g.idx_out[((long long)t_slot * N + me) * K + k] = mine;
     }
     if (!gather) return;
-    const float wgt = (mine >= 0 && mine < g.n_rows) ? 1.f : 0.f;
+    const float wgt = (mine >= 0 && mine < g.n_rows) ? 1.f : 0.f;     // (a row index outside the table means "no row", like an off-grid node)
     mine = (wgt != 0.f) ? mine : 0;
     const int H4 = g.H4;
     const uint32_t row_bytes = (uint32_t)H4 * 16u;
     const uint32_t my_row_off = (uint32_t)mine * row_bytes;          // < 4 GiB: checked by the host entry point
     const bool on = lane < H4;
     const uint32_t lane_off = (uint32_t)(on ? lane : H4 - 1) * 16u;  // every lane loads unconditionally (see sparse_rows_sum_kernel)
-    float4 sa = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
-    if (KT > 0) {
+    auto one_env = [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        if (S >= n_here) return;
+        float4 sa = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+        if (KT > 0) {
 #pragma unroll 1
-        for (int k0 = 0; k0 < KT; k0 += UNR) {
-            float4 va[UNR], vc[UNR];
+            for (int k0 = 0; k0 < KT; k0 += UNR) {
+                float4 va[UNR], vc[UNR];
 #pragma unroll
-            for (int j = 0; j < UNR; ++j) {
-                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, k0 + j) + lane_off;
-                va[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.wa) + off);
-                if (TWO) vc[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.wc) + off);
+                for (int j = 0; j < UNR; ++j) {
+                    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, S * KT + k0 + j) + lane_off;
+                    va[j] = enc_load4(reinterpret_cast<const char *>(g.wa) + off);
+                    if (TWO) vc[j] = enc_load4(reinterpret_cast<const char *>(g.wc) + off);
+                }
+#pragma unroll
+                for (int j = 0; j < UNR; ++j) {                        // k ascending
+                    const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), S * KT + k0 + j));
+                    enc_fma4(sa, va[j], w);
+                    if (TWO) enc_fma4(sc, vc[j], w);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < UNR; ++j) {                            // k ascending
-                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), k0 + j));
-                enc_fma4(sa, va[j], w);
-                if (TWO) enc_fma4(sc, vc[j], w);
+        } else {
+            for (int kk = 0; kk < K; ++kk) {
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, kk) + lane_off;
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), kk));
+                enc_fma4(sa, enc_load4(reinterpret_cast<const char *>(g.wa) + off), w);
+                if (TWO) enc_fma4(sc, enc_load4(reinterpret_cast<const char *>(g.wc) + off), w);
             }
         }
-    } else {
-        for (int k = 0; k < K; ++k) {
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_row_off, k) + lane_off;
-            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), k));
-            enc_fma4(sa, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.wa) + off), w);
-            if (TWO) enc_fma4(sc, *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.wc) + off), w);
+        if (!on) return;
+        const unsigned long long o = ((unsigned long long)t_slot * (unsigned long long)N + (unsigned long long)(m + S * m_stride)) * row_bytes + lane_off;
+        if (g.ba != nullptr) { const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.ba) + lane_off); sa.x += b.x; sa.y += b.y; sa.z += b.z; sa.w += b.w; }
+        if (g.relu6) sa = enc_relu6(sa);
+        enc_store4(reinterpret_cast<float *>(reinterpret_cast<char *>(g.oa) + o), sa);
+        if (TWO) {
+            if (g.bc != nullptr) { const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.bc) + lane_off); sc.x += b.x; sc.y += b.y; sc.z += b.z; sc.w += b.w; }
+            if (g.relu6) sc = enc_relu6(sc);
+            enc_store4(reinterpret_cast<float *>(reinterpret_cast<char *>(g.oc) + o), sc);
         }
-    }
-    if (!on) return;
-    const unsigned long long o = ((unsigned long long)t_slot * (unsigned long long)N + (unsigned long long)m) * row_bytes + lane_off;
-    if (g.ba != nullptr) { const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.ba) + lane_off); sa.x += b.x; sa.y += b.y; sa.z += b.z; sa.w += b.w; }
-    if (g.relu6) sa = enc_relu6(sa);
-    enc_store4(reinterpret_cast<float *>(reinterpret_cast<char *>(g.oa) + o), sa);
-    if (TWO) {
-        if (g.bc != nullptr) { const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(g.bc) + lane_off); sc.x += b.x; sc.y += b.y; sc.z += b.z; sc.w += b.w; }
-        if (g.relu6) sc = enc_relu6(sc);
-        enc_store4(reinterpret_cast<float *>(reinterpret_cast<char *>(g.oc) + o), sc);
-    }
+    };
+    one_env(std::integral_constant<int, 0>{});
+    if (NS > 1) one_env(std::integral_constant<int, (NS > 1 ? 1 : 0)>{});
 }
 
 #ifdef UAVENV_GATE_NOCAP        /* timing experiment: what the 96-VGPR cap costs (this build cannot run beside its partner) */
@@ -226,7 +239,10 @@ __global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_ga
                 __syncthreads();
                 GATE_STAMP(t, half, 3);
                 const bool gather = t + 1 < g.T;
-                for (int m = e_lo + wave; m < e_hi; m += kGateWaves) encode_env<KT, (KT == 44 ? 4 : 8), TWO>(g, p.out, m, U, BT, N, t + 1, gather);   // (UNR as in sparse_rows_sum_kernel: 24 = 3 x 8, 44 = 11 x 4)
+                // (UNR as in sparse_rows_sum_kernel: 24 = 3 x 8, 44 = 11 x 4; at 24 nodes a wavefront takes its two envs of the block, m and m + 8, at once)
+                constexpr int NS = (KT > 0 && 2 * KT <= 64) ? 2 : 1;
+                for (int m = e_lo + wave; m < e_hi; m += NS * kGateWaves)
+                    encode_env<KT, (KT == 44 ? 4 : 8), TWO, NS>(g, p.out, m, kGateWaves, (NS > 1 && m + kGateWaves < e_hi) ? 2 : 1, U, BT, N, t + 1, gather);
                 if (gather) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the encoded rows have left
                     __syncthreads();
