@@ -39,6 +39,9 @@ namespace uavk {
 // profiles/r04g_gated_kernels_alone_vgpr_caps.txt.)
 // ================================================================================================
 constexpr int kGateRows = 16, kGateWaves = 8;
+#ifndef UAVENV_GATE_UNR24
+#define UAVENV_GATE_UNR24 8      /* rows (x tables) in flight per wavefront at 24 nodes; 12: A/B build */
+#endif
 // What the step body loads coherently (env_packed_body's HO bits): the ACTIONS -- another kernel wrote them.  Not the env state and not the
 // observation the encoder reads back: only wavefronts of this workgroup touch them during the launch, they share one CU and its L1 (work-group
 // scope needs no cache bypass on gfx950), and the launch boundary took care of everything older.  UAVENV_GATE_COHERENT_STATE=1 (build flag,
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_ga
                 // (UNR as in sparse_rows_sum_kernel: 24 = 3 x 8, 44 = 11 x 4; at 24 nodes a wavefront takes its two envs of the block, m and m + 8, at once)
                 constexpr int NS = (KT > 0 && 2 * KT <= 64) ? 2 : 1;
                 for (int m = e_lo + wave; m < e_hi; m += NS * kGateWaves)
-                    encode_env<KT, (KT == 44 ? 4 : 8), TWO, NS>(g, p.out, m, kGateWaves, (NS > 1 && m + kGateWaves < e_hi) ? 2 : 1, U, BT, N, t + 1, gather);
+                    encode_env<KT, (KT == 44 ? 4 : UAVENV_GATE_UNR24), TWO, NS>(g, p.out, m, kGateWaves, (NS > 1 && m + kGateWaves < e_hi) ? 2 : 1, U, BT, N, t + 1, gather);
                 if (gather) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the encoded rows have left
                     __syncthreads();
