@@ -603,6 +603,24 @@ def test_graph_captured_rollout_equals_the_eager_rollout(first, second):
     assert r1.running_r is not None and r1.running_r == r2.running_r
 
 
+@pytest.mark.parametrize("n_envs", [1000, 4100], ids=lambda n: "%d_envs" % n)
+def test_persistent_rollout_with_a_ragged_last_block_equals_the_per_step_rollout(n_envs):
+    """Batches that are no multiple of the 16-env blocks (1000 = 62 blocks + 8 envs: the last pair has ONE, ragged block; 4100 = 256 + 1 pairs: more
+    pairs than CUs, the last one claimed by whichever workgroup finishes first): persistent rollout against the per-step launches, bit for bit."""
+    torch = _torch()
+    r1, r2 = _twin_runners(torch, n_envs, 5, max_step=9, first=dict(collect_launch="graph", persistent_rollout=True, pipeline_halves=False),
+                           second=dict(collect_launch="eager", persistent_rollout=False, pipeline_halves=False))
+    assert r1._persistent and not r2._persistent
+    for it in range(3):
+        b1, b2 = r1.collect(), r2.collect()
+        assert r1._persistent
+        for name, x, y in zip(("idx", "act", "rew", "boot"), b1, b2):
+            assert torch.equal(x, y), "%s differs in rollout %d" % (name, it)
+        assert np.array_equal(r1.env.get_state(), r2.env.get_state())
+        r1.update(*b1); r2.update(*b2)
+        assert torch.equal(r1.flat.w, r2.flat.w)
+
+
 @pytest.mark.parametrize("launch", ["eager", "graph"])
 def test_persistent_rollout_falls_back_when_its_kernels_cannot_run_side_by_side(launch, monkeypatch):
     """The two persistent rollout kernels wait for each other, so they must run at the same time.  With both in ONE stream (test hook) the
