@@ -693,7 +693,11 @@ def a2c_roofline(runner, envs, T):
                 "policy_frac_of_mfma_peak": flops / (pair_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "encoder_bytes": gbytes, "encoder_TBps": gbytes / (pair_ms * 1e-3) / 1e12,
                 "encoder_frac_of_gather_roof": gbytes / (pair_ms * 1e-3) / 1e12 / GATHER_CACHE_TBPS,
-                "note": "both kernels run for the whole rollout, so each rate is its work over the PAIR's time"}
+                "encoder_traffic_bytes_committed_pmc": 16.0e9 * (N / 8192.0) * ((T - 1) / 49.0),
+                "encoder_frac_of_fabric_gather_rate": gbytes / (pair_ms * 1e-3) / 1e12 / 7.4,
+                "note": "both kernels run for the whole rollout, so each rate is its work over the PAIR's time; traffic: FETCH_SIZE x 2 of the env kernel "
+                        "alone, profiles/r04pc_gated_kernels_alone_pmc_digest.txt (16.0 GB at 8192 x 50, scaled; a --pmc run serialises dispatches, so the "
+                        "pair itself cannot be counted); 7.4 TB/s: what this gather pattern reaches chip-wide (DESIGN 10c, 10e)"}
     return {"kernels": out, "persistent_rollout_pair": pair, "ms_per_rollout_covered": covered, "rollout_parts_on_streams": n_parts,
             "ms_per_rollout_covered_note": "sum of avg_us x calls; with the rollout pipelined over two streams the halves' kernels overlap, so the "
                                            "sum exceeds the wall time of a rollout + update",
