@@ -1475,7 +1475,7 @@ __device__ __forceinline__ bool head_gate_wait(uint32_t *word, uint32_t need, ui
     asm volatile("" ::: "memory");
     return ok;
 }
-#ifdef UAVAGENT_GATE_NOCAP      /* timing experiment: what the 96-VGPR cap costs (this build cannot run beside its partner) */
+#ifdef UAVAGENT_GATE_NOCAP      /* timing experiment: the kernel without its register cap (such a build cannot run beside its partner) */
 #define UAVAGENT_GATE_CAP
 #else
 #define UAVAGENT_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))

@@ -103,20 +103,9 @@ __device__ __forceinline__ void enc_store4(float *dst, const float4 &v) {      /
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst) + 1, u.w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A table row piece.  UAVENV_GATE_NT (build flag, A/B): as a non-temporal load, so that the 20 MB per XCD and block-step the encoder streams
-// through the L2 do not evict the 672 KB of weights the partner kernel's workgroups keep re-reading from it.
-__device__ __forceinline__ float4 enc_load4(const char *q) {
-#if defined(UAVENV_GATE_SKIP) && UAVENV_GATE_SKIP == 1
-    return float4{1.f, 2.f, 3.f, 4.f};
-#endif
-#ifdef UAVENV_GATE_NT
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(q));
-    return float4{v.x, v.y, v.z, v.w};
-#else
-    return *reinterpret_cast<const float4 *>(q);
-#endif
-}
+// A table row piece (an ordinary cached load: as non-temporal loads -- so as not to evict the partner kernel's weights from the L2 -- the
+// encoder alone took 4.19 instead of 3.13 ms per rollout, profiles/r04g_gated_kernels_alone_vgpr_caps.txt).
+__device__ __forceinline__ float4 enc_load4(const char *q) { return *reinterpret_cast<const float4 *>(q); }
 
 // The encoder, one wavefront for NS envs of the block: m, m + m_stride, ... (n_here <= NS of them exist).  KT > 0: B + U known at compile time (the
 // row loop unrolls by UNR around v_readlane).  NS = 2 (2 KT <= 64): the observation of BOTH envs is read and turned into row indices first --
@@ -200,7 +189,7 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
     if (NS > 1) one_env(std::integral_constant<int, (NS > 1 ? 1 : 0)>{});
 }
 
-#ifdef UAVENV_GATE_NOCAP        /* timing experiment: what the 96-VGPR cap costs (this build cannot run beside its partner) */
+#ifdef UAVENV_GATE_NOCAP        /* timing experiment: the kernel without its register cap (such a build cannot run beside its partner) */
 #define UAVENV_GATE_CAP
 #else
 #define UAVENV_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -230,14 +219,12 @@ __global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_ga
                 const int e_hi = (long long)(e_lo + kGateRows) < N ? e_lo + kGateRows : (int)N;
                 if (!gate_wait(g.gate_act + blk, (uint32_t)t + 1u, p)) return;
                 GATE_STAMP(t, half, 2);
-#if !defined(UAVENV_GATE_SKIP) || UAVENV_GATE_SKIP != 2      /* (timing experiments only: 2 = no env step, 1 = no table reads) */
                 const int w_lo = e_lo / EPW, n_w = (e_hi - 1) / EPW - w_lo + 1;
                 for (int w = wave; w < n_w; w += kGateWaves) {
                     env_packed_body<BT, MODE_STEP, PLC, true, false, false, kGateHO>(blob, g.actions + (long long)t * N, gid_of_u, N, U, EPW, Gr, B_rt, lane_magic, p,
                                                                                s_bs, wave, (long long)(w_lo + w), 0, 1, e_lo, e_hi, &po);
                     __builtin_amdgcn_wave_barrier();
                 }
-#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's output stores are in the L2
                 __syncthreads();
                 GATE_STAMP(t, half, 3);
