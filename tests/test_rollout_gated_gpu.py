@@ -241,3 +241,34 @@ def test_the_two_persistent_kernels_together_equal_the_step_by_step_rollout(shap
         if k != "reward":
             assert torch.equal(env.out[k], v), k
     assert np.array_equal(env.get_state(), ref.get_state())
+
+
+def test_rows_beyond_the_table_contribute_nothing():
+    """include/uavenv.h: a node whose row index is >= enc_rows contributes nothing (like a node off the grid) and is never dereferenced.  A table
+    that holds planes 0 and 1 only (the UAVs, and the UEs served by UAV 0): against the same sum formed step by step in torch, float32, node
+    order -- exactly."""
+    torch = _torch()
+    n, T, hid = 48, 3, 64
+    env = _env(n, 20)
+    ref = env.clone()
+    G, K = env.grid_n, env.nBS + env.nUE
+    rows = 2 * G * G
+    g = torch.Generator().manual_seed(5)
+    wa = (torch.rand(rows, hid, generator=g) - 0.5).to(env.device)
+    ba = (torch.rand(hid, generator=g) - 0.5).to(env.device)
+    act = torch.randint(0, env.action_space_dim, (T, n), generator=g, dtype=torch.int64).to(env.device)
+    b = _buffers(torch, env, T, hid)
+    env.rollout_gated(act, b["gate_act"], b["gate_obs"], b["claim"][0:1], wa, ba, b["out_a"], idx_out=b["idx"], reward_out=b["rew"], relu6=False)
+    torch.cuda.synchronize()
+    assert env.device_error() == 0
+    seen_beyond = 0
+    for t in range(T - 1):
+        ref.step(act[t])
+        idx = b["idx"][t + 1]                                       # checked against the learner's index kernel in the tests above
+        s = torch.zeros((n, hid), device=env.device)
+        for k in range(K):
+            ok = (idx[:, k] >= 0) & (idx[:, k] < rows)
+            s = s + torch.where(ok[:, None], wa[idx[:, k].clamp(0, rows - 1)], torch.zeros((), device=env.device))
+        seen_beyond += int((idx >= rows).sum())
+        assert torch.equal(b["out_a"][t + 1], s + ba), "slot %d" % (t + 1)
+    assert seen_beyond > 0                                          # UEs served by UAVs 1-3 do occur: the case was exercised
