@@ -1450,8 +1450,8 @@ __global__ __launch_bounds__(kHdThr, 1) void actor_head_kernel(const float *__re
 // wait until gate_obs[b] >= t + 1 (h1[t] of the block's rows is in memory), one 16-row tile exactly as actor_head_kernel<1> computes it
 // (same bits), actions stored through, s_waitcnt vmcnt(0), gate_act[b] = t + 1.  No kernel boundary, graph node or host call between a
 // step's kernels any more (a2c_single_thread.py:113-118 is a loop over independent workers).  Every wait is bounded: after spin_us the
-// wave stores kGateErr in the library's host-mapped error word and leaves (uavagent_device_error).  At most 128 VGPRs
-// (amdgpu_waves_per_eu(4, 4)): two of this kernel's waves and two of the env kernel's (<= 128 VGPRs each) share a SIMD's 512.
+// wave stores kGateErr in the library's host-mapped error word and leaves (uavagent_device_error).  At most UAVAGENT_GATE_VGPRS = 112
+// VGPRs (amdgpu_num_vgpr): two of this kernel's waves and two of the env kernel's (<= 144 VGPRs each) share a SIMD's 512.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kGateErr = 0x47415445u;      // "GATE"
 #ifdef UAVAGENT_GATE_STAMPS     /* diagnostic build (tools/gated_timeline.py): s_memrealtime of pair 0's events, same buffer as the env kernel's stamps */
@@ -1478,7 +1478,12 @@ __device__ __forceinline__ bool head_gate_wait(uint32_t *word, uint32_t need, ui
 #ifdef UAVAGENT_GATE_NOCAP      /* timing experiment: the kernel without its register cap (such a build cannot run beside its partner) */
 #define UAVAGENT_GATE_CAP
 #else
-#define UAVAGENT_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef UAVAGENT_GATE_VGPRS
+#define UAVAGENT_GATE_VGPRS 112     /* this kernel's share of a SIMD lane's 512 registers is 2 x this; the env kernel has the rest: 144
+                                     * (uavenv_gated_kernel.h).  112 + 144 against 128 + 128: the pair 3.75-3.78 against 3.86 ms per rollout, same box
+                                     * (profiles/r04gz_gated_pair_vgpr_split_sweep.txt): the env side is the one the rollout waits for */
+#endif
+#define UAVAGENT_GATE_CAP __attribute__((amdgpu_num_vgpr(UAVAGENT_GATE_VGPRS / 2)))   /* (gfx90a and later: the attribute counts VGPR + AGPR pairs) */
 #endif
 __global__ __launch_bounds__(kHdThr) UAVAGENT_GATE_CAP void actor_head_gated_kernel(const float *__restrict__ h1, const float *__restrict__ w2t, const float *__restrict__ b2,
                                                                       const float *__restrict__ w3t, const float *__restrict__ b3p,
@@ -1487,7 +1492,7 @@ __global__ __launch_bounds__(kHdThr) UAVAGENT_GATE_CAP void actor_head_gated_ker
                                                                       long long *__restrict__ action, uint32_t *gate_obs, uint32_t *gate_act,
                                                                       uint32_t *claim, uint32_t *err, uint32_t spin_us) {
     // (DYNAMIC LDS: with the 135 KB declared statically hipcc reasons that only two waves per SIMD can ever be resident, ignores
-    //  amdgpu_waves_per_eu and takes 143 VGPRs -- and then this kernel and its partner no longer fit one CU: 2 x 128 + 2 x 128)
+    //  its register cap and takes 143 VGPRs -- and then this kernel and its partner no longer fit one CU: 2 x 112 + 2 x 144)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n_blocks = (int)((n_rows + 15) / 16), n_pairs = (n_blocks + 1) >> 1;
     __shared__ int s_pair;

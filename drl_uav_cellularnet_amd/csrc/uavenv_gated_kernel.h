@@ -29,8 +29,8 @@ namespace uavk {
 // of the pair took 84 us instead of 76: half the wavefronts have half the row pieces in flight; one wavefront per (env, table) with all 24 pieces
 // issued at once: the same time as 16 at once; every second pair starting 8-36 us late so that the CUs' encoder phases do not coincide: 1 %;
 // non-temporal table loads: the encoder alone 4.19 instead of 3.13 ms per rollout.)
-// Launch: min(pairs, CUs) workgroups of kGateWaves = 8 wavefronts, at most 128 VGPRs (amdgpu_waves_per_eu(4, 4)); the partner the same: one
-// workgroup of each fills a CU's register file exactly (2 x 128 + 2 x 128 per SIMD lane), and that is how an idle chip is filled -- one pair per
+// Launch: min(pairs, CUs) workgroups of kGateWaves = 8 wavefronts, at most UAVENV_GATE_VGPRS = 144 VGPRs (amdgpu_num_vgpr, which counts register
+// PAIRS on gfx90a and later); the partner at most 112: one workgroup of each fills a CU's register file exactly (2 x 144 + 2 x 112 per SIMD lane), and that is how an idle chip is filled -- one pair per
 // CU.  Residency: nothing here DEPENDS on that placement.  Pairs of blocks are claimed from a counter in arrival order by both kernels, so
 // whichever workgroups are resident hold the lowest unfinished pairs on both sides; if the dispatcher ever puts two of these workgroups on one
 // CU (and the partner's therefore on none), the pairs left over simply start when a workgroup has finished its rollout -- slower, never stuck.
@@ -192,7 +192,10 @@ __device__ __forceinline__ void encode_env(const GatedParams &g, const OutPtrs &
 #ifdef UAVENV_GATE_NOCAP        /* timing experiment: the kernel without its register cap (such a build cannot run beside its partner) */
 #define UAVENV_GATE_CAP
 #else
-#define UAVENV_GATE_CAP __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef UAVENV_GATE_VGPRS
+#define UAVENV_GATE_VGPRS 144       /* this kernel's share of a SIMD lane's 512 registers is 2 x this; the policy kernel has the rest (112) */
+#endif
+#define UAVENV_GATE_CAP __attribute__((amdgpu_num_vgpr(UAVENV_GATE_VGPRS / 2)))       /* (gfx90a and later: the attribute counts VGPR + AGPR pairs) */
 #endif
 template <int BT, bool PLC, int KT, bool TWO>
 __global__ __launch_bounds__(64 * kGateWaves) UAVENV_GATE_CAP void env_kernel_gated(char *blob, const int8_t *gid_of_u, long long N, int U, int EPW, int Gr, int B_rt,

@@ -158,7 +158,7 @@ int uavagent_actor_head_f32(const float *h1, const float *w2t, const float *b2, 
  * per-step arrays are [n_steps][n_rows][...] contiguous: h1, h2_out [T][n_rows][200], uniforms and actions_out [T][n_rows], logits_out
  * [T][n_rows][ld_logits].  n_rows a multiple of 4.  The caller zeroes gate_actions and presets gate_obs (1 where h1[0] is ready) before the
  * launch, zeroes `claim` (one word: pairs of blocks are handed out in arrival order, like the env kernel's) and launches the two kernels on
- * DIFFERENT streams (or parallel graph branches).  min(blocks / 2, CUs) workgroups of 8 wavefronts, <= 128 VGPRs, 135 KB of LDS: one per CU,
+ * DIFFERENT streams (or parallel graph branches).  min(blocks / 2, CUs) workgroups of 8 wavefronts, <= 112 VGPRs, 135 KB of LDS: one per CU,
  * beside one workgroup of the env kernel.  Every wait is bounded (spin_us of the 100 MHz clock; 0 = 2 s):
  * a partner that never arrives leaves 0x47415445 "GATE" in the library's error word (uavagent_device_error; uavagent_device_error_clear)
  * and the kernel exits.  uavagent_gate_prepare() allocates that host-mapped word once per process -- call it outside any stream capture. */

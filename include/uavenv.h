@@ -241,7 +241,7 @@ int uavenv_debug_schedule(int64_t n_wavefronts, int64_t n_slots, int n_steps, in
  * 2 s): a partner that never arrives -- not launched, not co-resident, crashed -- leaves error word 0x47415445 "GATE", the kernel exits and
  * the handle answers UAVENV_E_DEVICE until uavenv_set_state (uavenv_device_error).  The caller must launch both kernels on DIFFERENT streams
  * (or parallel branches of one graph) so that they can run at the same time; this one occupies min(blocks / 2, CUs) workgroups of 8
- * wavefronts x <= 128 VGPRs, the partner should too: one workgroup of each then fills a CU exactly.  Correctness does not depend on that
+ * wavefronts x <= 144 VGPRs, the partner 8 x <= 112: one workgroup of each then fills a CU exactly.  Correctness does not depend on that
  * placement: both kernels CLAIM their pairs of blocks from a counter in arrival order (claim_dev here, the partner's own word there), so the
  * lowest unfinished pairs are always held by resident workgroups on both sides.
  * The encoder is the first dense layer of main.py:147 / :153 applied to the raveled one-hot state of main.py:190 without forming it:
