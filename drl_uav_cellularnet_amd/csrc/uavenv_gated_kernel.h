@@ -26,7 +26,8 @@ namespace uavk {
 // env, lane = float4 column group, UNR rows (x tables) in flight: the arithmetic and its order are those of the learner's
 // sparse_rows_sum_kernel (agent_kernels.hip), results are bit-identical; (4) publish.
 // (Tried and not kept, all bit-identical, profiles/r04g_*: four wavefronts stepping while four encode, counters in LDS between them -- a step
-// of the pair took 84 us instead of 76: half the wavefronts have half the row pieces in flight; one wavefront per (env, table) with all 24 pieces
+// of the pair took 84 us instead of 76: half the wavefronts have half the row pieces in flight; the same with EIGHT encoders + four steppers, 12
+// wavefronts at <= 96 VGPRs beside the policy kernel's 2 x 112: the pair 4.43-4.54 against 3.75 ms, the step body spills 68 registers at 96; one wavefront per (env, table) with all 24 pieces
 // issued at once: the same time as 16 at once; every second pair starting 8-36 us late so that the CUs' encoder phases do not coincide: 1 %;
 // non-temporal table loads: the encoder alone 4.19 instead of 3.13 ms per rollout.)
 // Launch: min(pairs, CUs) workgroups of kGateWaves = 8 wavefronts, at most UAVENV_GATE_VGPRS = 144 VGPRs (amdgpu_num_vgpr, which counts register
